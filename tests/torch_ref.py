@@ -1,0 +1,78 @@
+"""Independent torch (CPU, autograd) build of the reference graph, used ONLY to pin the NumPy
+oracle (tests/test_oracle_vs_torch.py).  It shares the op list in oracle/arch.py but none of
+the oracle's arithmetic: convs are F.conv2d, gradients come from torch.autograd."""
+import torch
+import torch.nn.functional as F
+
+from oracle.arch import encoder_ops
+from oracle import model as om
+
+
+def forward_loss(cfg, params, image, caption):
+    """params: dict name -> torch tensor (requires_grad where wanted), reference layouts."""
+    p = params
+    enc, enc_out, C = encoder_ops(cfg['encoder'])
+    t = {0: image}
+    for op in enc:
+        if op[0] == 'conv_bn':
+            _, name, src, dst, cin, cout, k, stride, pad, groups, act = op
+            y = F.conv2d(t[src], p[name + '_weights'], None, stride, pad, 1, groups)
+            mean = y.mean(dim=(0, 2, 3), keepdim=True)
+            var = y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+            y = (y - mean) / torch.sqrt(var + 1e-5)
+            y = y * p[name + '_bn_scale'][None, :, None, None] + p[name + '_bn_offset'][None, :, None, None]
+            if act == 'relu6':
+                y = torch.clamp(y, 0, 6)
+            elif act == 'relu':
+                y = torch.relu(y)
+            t[dst] = y
+        elif op[0] == 'add':
+            _, a, b, dst, act = op
+            y = t[a] + t[b]
+            t[dst] = torch.relu(y) if act == 'relu' else y
+        else:
+            _, src, dst = op
+            t[dst] = F.max_pool2d(t[src], 3, 2, 1)
+    feat = t[enc_out]
+    B = feat.shape[0]
+    A = feat.reshape(B, C, -1).permute(0, 2, 1)
+
+    def fc(name, x):
+        return x @ p[name + '.w_0'] + p[name + '.b_0']
+
+    V0 = torch.relu(fc(om.FC_IMG_EMBED, A))
+    g = torch.relu(fc(om.FC_IMG_GLOBAL, A.mean(1)))
+    Vt = torch.tanh(fc(om.FC_IMG_FEAT, V0))
+    Ve = fc(om.FC_IMG_FEAT_EMB, V0)
+    H = cfg['hidden']
+    hid = torch.zeros(B, H, dtype=feat.dtype)
+    cell = torch.zeros(B, H, dtype=feat.dtype)
+    target = caption[:, 1:]
+    source = caption[:, :-1]
+    mask = (target != cfg['padding_idx']).to(feat.dtype)
+    logits = []
+    emb_table = p['word_embedding']
+    for s in range(cfg['sentence_length'] - 1):
+        w = source[:, s]
+        emb = emb_table[w] * (w != cfg['padding_idx']).to(feat.dtype)[:, None]
+        xt = torch.cat([emb, g], -1)
+        gates = torch.cat([xt, hid], -1) @ p['lstm_w'] + p['lstm_b']
+        i, f, o, gg = gates.split(H, dim=-1)
+        c = torch.sigmoid(f) * cell + torch.sigmoid(i) * torch.tanh(gg)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        sg = torch.sigmoid(fc(om.FC_P_WORD, xt) + fc(om.FC_P_HIDDEN, hid))
+        sentinel = sg * torch.tanh(c)
+        hid, cell = h, c
+        p_hid = torch.tanh(fc(om.FC_P_HID, h))
+        hid_emb = fc(om.FC_HID_EMB, p_hid)
+        sent_emb = fc(om.FC_SENT_EMB, sentinel)
+        z = torch.tanh(torch.cat([Ve, sent_emb[:, None]], 1) + hid_emb[:, None])
+        e = fc(om.FC_ALPHA, z)
+        alpha = torch.softmax(e, dim=-1 if cfg['attention'] == 'singleton' else 1)
+        ctx = (torch.cat([Vt, sentinel[:, None]], 1) * alpha).mean(1)
+        out = torch.tanh(fc(om.FC_OUT, ctx + p_hid))
+        logits.append(fc(om.FC_PROJ, out) @ emb_table.t() + p['out_fc_bias'])
+    logits = torch.stack(logits, 1)
+    ce = F.cross_entropy(logits.reshape(-1, logits.shape[-1]), target.reshape(-1), reduction='none')
+    loss = (ce.reshape(target.shape) * mask).sum() / mask.sum()
+    return loss, logits
