@@ -1,0 +1,200 @@
+/* capmi.h -- C ABI of libcapmi.so: the MI355X (gfx950) kernels behind the captioning hot path.
+ *
+ * The reference (Chgtaxihe/MyImageCaptioningModel) has no FFI of its own: every op below is a
+ * PaddlePaddle-1.8 `fluid.layers.*` call that Paddle lowers to its CUDA/cuDNN kernels.  Each
+ * entry point names the reference call site(s) it replaces (IC/ = ImageCaptioning/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors); nothing is
+ *     allocated or freed here; every call only enqueues work on `stream` (a hipStream_t) and
+ *     returns: 0 = ok, non-zero = error (text via capmi_last_error()).  Never throws.
+ *   - `dtype` selects the activation/weight storage type: CAPMI_F32 (reference precision, exact
+ *     f32 MFMA) or CAPMI_BF16 (bf16 storage, f32 accumulate).  Statistics, losses, gradients of
+ *     parameters and optimizer state are always f32.
+ *   - encoder activations are NHWC ([B,H,W,C], C fastest); GEMM weights are [N][K] with K
+ *     fastest, K ordered (kh, kw, cin) for convolutions.
+ *   - optional pointers may be NULL where stated.
+ */
+#ifndef CAPMI_H
+#define CAPMI_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAPMI_ABI_VERSION 1
+enum { CAPMI_F32 = 0, CAPMI_BF16 = 1 };
+enum { CAPMI_ACT_NONE = 0, CAPMI_ACT_RELU = 1, CAPMI_ACT_RELU6 = 2, CAPMI_ACT_TANH = 3, CAPMI_ACT_SIGMOID = 4 };
+
+int capmi_version(void);
+const char* capmi_last_error(void);
+
+/* Geometry of one implicit-GEMM convolution pass over an NHWC tensor.
+ * Output pixel (b,ho,wo), tap (r,q) reads input pixel hn = ho*sd - pad + r (same for w); with
+ * `up` > 1 (data-gradient of a strided conv) the tap is valid only if hn % up == 0 and reads
+ * hn/up.  A plain GEMM is Hi=Wi=Ho=Wo=kh=kw=sd=up=1, pad=0, B = rows. */
+typedef struct {
+    int B, Hi, Wi, Cin;   /* input tensor [B,Hi,Wi,*], Cin channels used               */
+    int Ho, Wo;           /* output spatial size                                       */
+    int kh, kw, sd, up, pad;
+    int ldx;              /* elements between consecutive input pixels (>= Cin)        */
+} capmi_conv_geom;
+
+/* Y[m][n] = epilogue( sum_k A(m,k) * W[n][k] ),  m=(b,ho,wo), k=(r,q,c), A gathered by `g`.
+ * Replaces: fluid.layers.conv2d dense calls (IC/model/MobileNetV2.py:99-109) forward and their
+ * data gradients; layers.fc / mul (IC/model/model_adaAttention_aic.py:24,52,53,89,90,99,102,
+ * 104,107,115,196,198), the lstm_unit gate fc (:87-88) and the tied vocabulary projection
+ * matmul(transpose_y=True) (:25), forward and data-gradient.
+ * Epilogue, in order: (+ bias[n]) (+ addend[m][n]) -> optional per-column f32 sum / sum-of-
+ * squares accumulation into stats[0..N) / stats[N..2N) (atomic; fused batch-norm statistics)
+ * -> act -> (* act'(ysaved[m][n]) when dact != NONE: ysaved holds the forward OUTPUT of that
+ * activation) -> store as `dtype`, or f32 when out_f32.
+ * Requires Cin % (16/sizeof(elem)) == 0 and ldx, ldw likewise; N, M arbitrary. */
+int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom* g,
+                   int N, int ldw, int ldy,
+                   const float* bias, const void* addend, int ld_addend,
+                   const void* ysaved, int ld_saved, float* stats,
+                   int act, int dact, int out_f32, int dtype, void* stream);
+
+/* dW[n][k] (+)= sum_m dY[m][n] * A(m,k): weight gradient (f32 output, atomic accumulation --
+ * the caller zeroes dW once per step).  Replaces conv2d_grad's filter gradient and mul_grad's
+ * weight gradient for the same call sites as capmi_igemm_nt.  dY is [M][ldy] in `dtype`. */
+int capmi_igemm_tn_wgrad(const void* x, const void* dy, float* dw, const capmi_conv_geom* g,
+                         int N, int ldy, int lddw, int dtype, void* stream);
+
+/* out[n] += sum_m a[m][n] (f32 atomic accumulate): bias gradients (elementwise_add_grad). */
+int capmi_colsum(const void* a, int M, int N, int lda, float* out, int dtype, void* stream);
+
+/* Stem im2col: NCHW f32 image (the reference feed, IC/reader.py:45-47) -> [B*Ho*Wo][Kpad]
+ * patch matrix in `dtype`, k=(r,q,c), zero padded to Kpad. */
+int capmi_im2col_stem(const float* img, void* out, int B, int C, int H, int W, int k, int stride,
+                      int pad, int Ho, int Wo, int Kpad, int dtype, void* stream);
+
+/* Depthwise 3x3 (fluid.layers.conv2d groups=C use_cudnn=False, IC/model/MobileNetV2.py:155-164).
+ * w is [3][3][C] f32/bf16 as `dtype`; dw is f32 [3][3][C] (atomic accumulate). */
+int capmi_dwconv3x3_fwd(const void* x, const void* w, void* y, int B, int Hi, int Wi, int C,
+                        int stride, int Ho, int Wo, int dtype, void* stream);
+int capmi_dwconv3x3_bwd_data(const void* dy, const void* w, void* dx, int B, int Hi, int Wi, int C,
+                             int stride, int Ho, int Wo, int accumulate, int dtype, void* stream);
+int capmi_dwconv3x3_bwd_weight(const void* x, const void* dy, float* dw, int B, int Hi, int Wi, int C,
+                               int stride, int Ho, int Wo, int dtype, void* stream);
+
+/* 3x3 stride-2 pad-1 max pool, NHWC (ResNet stem; build-defined extension). idx: uint8 tap. */
+int capmi_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int B, int Hi, int Wi, int C,
+                           int Ho, int Wo, int dtype, void* stream);
+int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int Hi, int Wi, int C,
+                           int Ho, int Wo, int dtype, void* stream);
+
+/* Batch norm, train mode (fluid.layers.batch_norm, IC/model/MobileNetV2.py:112-117) over
+ * x [M][C] (M = B*H*W), fused with relu/relu6 (:119) and the residual add (:123-124).
+ *   bn_stats   : stats[0..C) += sum_m x, stats[C..2C) += sum_m x^2          (f32 atomics)
+ *   bn_finalize: mean/biased var from stats and count M; writes saved_mean, saved_invstd,
+ *                coef_a = scale*invstd, coef_b = offset - mean*coef_a, and updates the running
+ *                stats with momentum (run = m*run + (1-m)*batch)
+ *   bn_apply   : y = act(coef_a*x + coef_b (+ res))
+ *   bn_bwd_reduce: with dz = dy * act'(y): red[0..C) += sum dz, red[C..2C) += sum dz*xhat
+ *   bn_bwd_apply : dx (+)= scale*invstd*(dz - red0/M - xhat*red1/M); optional dres (+)= dz;
+ *                  dscale/doffset = red1/red0 are read by the optimizer straight from `red`. */
+int capmi_bn_stats(const void* x, int M, int C, float* stats, int dtype, void* stream);
+int capmi_bn_finalize(const float* stats, int M, int C, const float* scale, const float* offset,
+                      float* run_mean, float* run_var, float momentum, float eps,
+                      float* saved_mean, float* saved_invstd, float* coef_a, float* coef_b,
+                      int update_running, void* stream);
+int capmi_bn_apply(const void* x, const float* coef_a, const float* coef_b, const void* res, void* y,
+                   int M, int C, int act, int dtype, void* stream);
+int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y, const float* saved_mean,
+                        const float* saved_invstd, float* red, int M, int C, int act, int dtype,
+                        void* stream);
+int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, const float* saved_mean,
+                       const float* saved_invstd, const float* scale, const float* red,
+                       void* dx, int dx_accumulate, void* dres, int dres_accumulate,
+                       int M, int C, int act, int dtype, void* stream);
+
+/* Elementwise helpers. add_act: y = act(a + b) (MobileNetV2 shortcut, :123-124);
+ * add_act_bwd: d (+)= dy * act'(y).  mean_rows: out[b][c] = mean_k x[b][k][c] (reduce_mean,
+ * model_adaAttention_aic.py:197) and its broadcast gradient. */
+int capmi_add_act(const void* a, const void* b, void* y, int64_t n, int act, int dtype, void* stream);
+int capmi_act_bwd(const void* dy, const void* y, void* dx, int accumulate, int64_t n, int act, int dtype, void* stream);
+int capmi_mean_rows(const void* x, void* out, int B, int K, int C, int dtype, void* stream);
+int capmi_mean_rows_bwd(const void* dout, void* dx, int B, int K, int C, int dtype, void* stream);
+
+/* fluid.embedding(padding_idx) (model_adaAttention_aic.py:28-32): out[m][0..E) = table[ids[m]]
+ * (zeros for padding_idx), written with row stride ldo.  bwd: dtable[ids[m]] += dout[m] (f32
+ * atomics; padding rows skipped). */
+int capmi_embedding_fwd(const int64_t* ids, const void* table, void* out, int M, int E, int V,
+                        int ldo, int padding_idx, int dtype, void* stream);
+int capmi_embedding_bwd(const int64_t* ids, const void* dout, float* dtable, int M, int E, int V,
+                        int ldo, int padding_idx, int dtype, void* stream);
+/* dst[t][b][col0 + j] = src[b][j] for t in [0,T): the concat([word_emb, global_img_feat]) of
+ * model_adaAttention_aic.py:86 batched over time; bwd: dsrc[b][j] = sum_t ddst[t][b][col0+j]. */
+int capmi_bcast_rows(const void* src, void* dst, int T, int B, int H, int ldd, int col0, int dtype, void* stream);
+int capmi_bcast_rows_bwd(const void* ddst, void* dsrc, int T, int B, int H, int ldd, int col0, int dtype, void* stream);
+
+/* lstm_unit op (model_adaAttention_aic.py:87-88) on pre-computed gate pre-activations
+ * gates[B][4H] (blocks i,f,o,g; forget_bias 0): c = s(f)c' + s(i)tanh(g); h = s(o)tanh(c). */
+int capmi_lstm_cell_fwd(const void* gates, const void* c_prev, void* h, void* c, int B, int H,
+                        int dtype, void* stream);
+/* Backward of the cell: dh = total gradient on h_t, dc_in = gradient on c_t from later steps and
+ * the sentinel (NULL = 0); c_prev NULL = zero state.  Writes dgates [B][4H]; dc_prev (optional)
+ * receives sigmoid(f)*dc_total, added to its old contents when dc_prev_accumulate. */
+int capmi_lstm_cell_bwd(const void* gates, const void* c_prev, const void* c, const void* dh,
+                        const void* dc_in, void* dgates, void* dc_prev, int dc_prev_accumulate,
+                        int B, int H, int dtype, void* stream);
+/* visual sentinel (:91-92): s = sigmoid(sgpre) * tanh(c); bwd -> dsgpre, dc. */
+int capmi_sentinel_fwd(const void* sgpre, const void* c, void* s, int64_t n, int dtype, void* stream);
+int capmi_sentinel_bwd(const void* ds, const void* sgpre, const void* c, void* dsgpre, void* dc,
+                       int64_t n, int dtype, void* stream);
+
+/* Adaptive attention over the K image slots + the sentinel slot (model_adaAttention_aic.py:
+ * 97-113).  Rows are time-major: row m = t*B + b reads image b.
+ *   slots = 0 ('singleton', reference-faithful quirk Q1: softmax over the size-1 axis, alpha==1)
+ *           ctx = (sum_k Vt[b,k,:] + s) / (K+1)
+ *   slots = 1 (intended attention): z = tanh([Ve[b]; se] + q); e = z.w10 + b10;
+ *           alpha = softmax over the K+1 slots; ctx = mean_k(alpha_k * [Vt[b]; s])
+ * out[m] = ctx + p[m] (the fc input of :115).  alpha [M][K+1] f32 is saved for backward. */
+int capmi_ada_attention_fwd(const void* Ve, const void* Vt, const void* q, const void* se,
+                            const void* s, const void* p, const void* w10, const float* b10,
+                            void* out, float* alpha, int T, int B, int K, int H, int slots,
+                            int dtype, void* stream);
+/* Given dout [M][H]: ds (written), dVt/dVe [B][K][H] (written), dq, dse [M][H] (written; slots
+ * only), dw10 [H] / db10 [1] (f32 atomic accumulate; slots only).  de [M][K+1] f32 workspace. */
+int capmi_ada_attention_bwd(const void* Ve, const void* Vt, const void* q, const void* se,
+                            const void* s, const void* w10, const float* alpha, const void* dout,
+                            void* ds, void* dVt, void* dVe, void* dq, void* dse,
+                            float* dw10, float* db10, float* de,
+                            int T, int B, int K, int H, int slots, int dtype, void* stream);
+
+/* softmax_with_cross_entropy + mask/sum/div (model_adaAttention_aic.py:165-182,205-212) over
+ * f32 logits [M][V]: row_loss[m] = (lse - logit[target]) * (target != padding_idx);
+ * loss_out[0] = sum row_loss / count(mask) computed by capmi_xent_finalize; bwd writes
+ * dlogits = (softmax - onehot) * mask / count in `dtype`, row stride ldd >= V (columns V..ldd
+ * are zero-filled so the padded matrix can feed the MFMA kernels); ld = logits row stride. */
+int capmi_softmax_xent_fwd(const float* logits, const int64_t* target, float* row_loss,
+                           float* row_lse, int M, int V, int ld, int padding_idx, void* stream);
+int capmi_xent_finalize(const float* row_loss, const int64_t* target, float* loss_out,
+                        float* count_out, int M, int padding_idx, void* stream);
+int capmi_softmax_xent_bwd(const float* logits, const int64_t* target, const float* row_lse,
+                           const float* count, void* dlogits, int M, int V, int ld, int ldd,
+                           int padding_idx, int dtype, void* stream);
+/* layers.argmax (:120): lowest index on ties; ids_out int64 [M], also f32 copy (quirk Q2). */
+int capmi_argmax(const float* logits, int64_t* ids_out, float* ids_f32, int ld_f32, int M, int V, int ld, void* stream);
+
+/* fluid.optimizer.Adam, Paddle-1.8 form, over one flat f32 range (IC/train.py:26-31,45) with
+ * optional GradientClipByValue (:42-43; clip <= 0 disables):
+ *   lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ *   p -= lr_t * m / (sqrt(v) + eps).   lr_t is computed on the host and passed in.
+ * grad_scale multiplies g first (1/N of ParallelExecutor's CoeffNumDevice, IC/train.py:121-124). */
+int capmi_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1,
+               float b2, float eps, float clip, float grad_scale, void* stream);
+/* Weight shadows for the MFMA kernels: capmi_cast = elementwise f32 -> `dtype`;
+ * capmi_weight_dgrad_form: W [N][kh][kw][C] f32 -> the data-gradient operand [C][kh][kw][ldt]
+ * (taps flipped; columns N..ldt zero; ldt > N only for 1x1 weights). */
+int capmi_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
+int capmi_weight_dgrad_form(const float* w, void* wt, int N, int kh, int kw, int C, int ldt, int dtype, void* stream);
+int capmi_fill_f32(float* p, float value, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPMI_H */

@@ -1,0 +1,132 @@
+"""ctypes binding of libcapmi.so (the C ABI declared in include/capmi.h).
+
+The library is the product path: if it is missing or a symbol is absent this module raises --
+there is no CPU/eager fallback anywhere in the package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcapmi.so')
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_RELU6, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+ACT_CODES = {None: ACT_NONE, 'relu': ACT_RELU, 'relu6': ACT_RELU6, 'tanh': ACT_TANH, 'sigmoid': ACT_SIGMOID}
+
+
+class ConvGeom(ctypes.Structure):
+    """capmi_conv_geom (include/capmi.h)."""
+    _fields_ = [(n, ctypes.c_int) for n in
+                ('B', 'Hi', 'Wi', 'Cin', 'Ho', 'Wo', 'kh', 'kw', 'sd', 'up', 'pad', 'ldx')]
+
+
+def gemm_geom(rows, K, ldx=None):
+    """Geometry of a plain row-major GEMM A[rows][K] (row stride ldx)."""
+    return ConvGeom(rows, 1, 1, K, 1, 1, 1, 1, 1, 1, 0, K if ldx is None else ldx)
+
+
+_p, _i, _f, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+_g = ctypes.POINTER(ConvGeom)
+
+# name -> argument ctypes (the trailing `void* stream` included).  Must list every symbol of capmi.h.
+SIGNATURES = {
+    'capmi_igemm_nt': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
+    'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _i, _p],
+    'capmi_colsum': [_p, _i, _i, _i, _p, _i, _p],
+    'capmi_im2col_stem': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_dwconv3x3_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_dwconv3x3_bwd_data': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_dwconv3x3_bwd_weight': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_maxpool3x3s2_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_maxpool3x3s2_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_bn_stats': [_p, _i, _i, _p, _i, _p],
+    'capmi_bn_finalize': [_p, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p],
+    'capmi_bn_apply': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_bn_bwd_reduce': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_bn_bwd_apply': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    'capmi_add_act': [_p, _p, _p, _l, _i, _i, _p],
+    'capmi_act_bwd': [_p, _p, _p, _i, _l, _i, _i, _p],
+    'capmi_mean_rows': [_p, _p, _i, _i, _i, _i, _p],
+    'capmi_mean_rows_bwd': [_p, _p, _i, _i, _i, _i, _p],
+    'capmi_embedding_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_embedding_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_bcast_rows': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_bcast_rows_bwd': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_lstm_cell_fwd': [_p, _p, _p, _p, _i, _i, _i, _p],
+    'capmi_lstm_cell_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_sentinel_fwd': [_p, _p, _p, _l, _i, _p],
+    'capmi_sentinel_bwd': [_p, _p, _p, _p, _p, _l, _i, _p],
+    'capmi_ada_attention_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_ada_attention_bwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                _i, _i, _i, _i, _i, _i, _p],
+    'capmi_softmax_xent_fwd': [_p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_xent_finalize': [_p, _p, _p, _p, _i, _i, _p],
+    'capmi_softmax_xent_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_argmax': [_p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_adam': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
+    'capmi_cast': [_p, _p, _l, _i, _p],
+    'capmi_weight_dgrad_form': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_fill_f32': [_p, _f, _l, _p],
+}
+
+
+class CapmiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libcapmi.so once; raises CapmiError when the extension is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CapmiError('libcapmi.so not found at %s -- run __graft_entry__.build() '
+                             '(myimagecaptioningmodel_amd/csrc/build.sh); there is no fallback path' % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.capmi_version.restype = ctypes.c_int
+        L.capmi_last_error.restype = ctypes.c_char_p
+        for name, args in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().capmi_last_error().decode()
+
+
+def call(name, *args):
+    """Calls one entry point (the stream is the last argument) and raises on a non-zero return."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise CapmiError('%s failed (%d): %s' % (name, rc, last_error()))
+
+
+class Plan:
+    """A recorded launch sequence: (function, args-without-stream).  `run(stream)` replays it on
+    a HIP stream; static shapes make the whole sequence capturable in a hipGraph."""
+
+    def __init__(self):
+        self.calls = []
+        self._keep = []      # keeps ConvGeom structs / tensors alive
+
+    def add(self, name, *args):
+        fn = getattr(lib(), name)
+        self.calls.append((fn, name, args))
+        self._keep.append(args)
+
+    def extend(self, other):
+        self.calls.extend(other.calls)
+        self._keep.extend(other._keep)
+
+    def run(self, stream):
+        for fn, name, args in self.calls:
+            if fn(*args, stream) != 0:
+                raise CapmiError('%s failed: %s' % (name, last_error()))
+
+    def __len__(self):
+        return len(self.calls)

@@ -1,0 +1,677 @@
+// Decoder-side kernels for gfx950: embedding gather/scatter, LSTM cell, visual sentinel, adaptive
+// attention (LDS-staged, wave reductions), masked softmax cross-entropy, argmax, column sums.
+// Rows of every [M][*] operand are time-major (m = t*B + b).
+#include "common.h"
+
+// ------------------------------------------------------------------ embedding
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ table, T* out,
+                                                            int M, int cpr, int V, int ldo, int padding_idx) {
+    constexpr int VEC = Vec<T>::N;
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * cpr) return;
+    int m = e / cpr, cc = e % cpr;
+    int64_t id = ids[m];
+    Vec<T> v = (id == padding_idx || id < 0 || id >= V) ? vzero<T>() : vload<T>(table + (id * cpr + cc) * VEC);
+    vstore<T>(out + (int64_t)m * ldo + cc * VEC, v);
+}
+extern "C" int capmi_embedding_fwd(const int64_t* ids, const void* table, void* out, int M, int E, int V, int ldo,
+                                   int padding_idx, int dtype, void* stream) {
+    CAPMI_CHECK(ids && table && out, "capmi_embedding_fwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_embedding_fwd", {
+        CAPMI_CHECK(E % Vec<T>::N == 0 && ldo % Vec<T>::N == 0, "capmi_embedding_fwd: E/ldo not multiples of the vector width");
+        int cpr = E / Vec<T>::N;
+        hipLaunchKernelGGL(embedding_fwd_kernel<T>, dim3(cdiv((int64_t)M * cpr, 256)), dim3(256), 0, (hipStream_t)stream, ids, (const T*)table, (T*)out, M, cpr, V, ldo, padding_idx);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_embedding_fwd");
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout, float* dtable,
+                                                            int M, int E, int V, int ldo, int padding_idx) {
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= M * E) return;
+    int m = e / E, j = e % E;
+    int64_t id = ids[m];
+    if (id == padding_idx || id < 0 || id >= V) return;
+    atomicAdd(&dtable[id * E + j], to_f32(dout[(int64_t)m * ldo + j]));
+}
+extern "C" int capmi_embedding_bwd(const int64_t* ids, const void* dout, float* dtable, int M, int E, int V, int ldo,
+                                   int padding_idx, int dtype, void* stream) {
+    CAPMI_CHECK(ids && dout && dtable, "capmi_embedding_bwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_embedding_bwd", {
+        hipLaunchKernelGGL(embedding_bwd_kernel<T>, dim3(cdiv((int64_t)M * E, 256)), dim3(256), 0, (hipStream_t)stream, ids, (const T*)dout, dtable, M, E, V, ldo, padding_idx);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_embedding_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ broadcast of the global image feature over time
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_rows_kernel(const T* __restrict__ src, T* dst, int T_, int B, int cpr, int ldd, int col0) {
+    constexpr int VEC = Vec<T>::N;
+    int64_t n = (int64_t)T_ * B * cpr;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        int cc = (int)(e % cpr);
+        int64_t row = e / cpr;
+        int b = (int)(row % B);
+        vstore<T>(dst + row * ldd + col0 + cc * VEC, vload<T>(src + ((int64_t)b * cpr + cc) * VEC));
+    }
+}
+extern "C" int capmi_bcast_rows(const void* src, void* dst, int T_, int B, int H, int ldd, int col0, int dtype, void* stream) {
+    CAPMI_CHECK(src && dst, "capmi_bcast_rows: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_bcast_rows", {
+        CAPMI_CHECK(H % Vec<T>::N == 0 && ldd % Vec<T>::N == 0 && col0 % Vec<T>::N == 0, "capmi_bcast_rows: misaligned");
+        int cpr = H / Vec<T>::N;
+        hipLaunchKernelGGL(bcast_rows_kernel<T>, dim3(ew_grid((int64_t)T_ * B * cpr)), dim3(256), 0, (hipStream_t)stream, (const T*)src, (T*)dst, T_, B, cpr, ldd, col0);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bcast_rows");
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bcast_rows_bwd_kernel(const T* __restrict__ ddst, T* dsrc, int T_, int B, int cpr, int ldd, int col0) {
+    constexpr int VEC = Vec<T>::N;
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * cpr) return;
+    int b = e / cpr, cc = e % cpr;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int t = 0; t < T_; ++t) {
+        Vec<T> g = vload<T>(ddst + ((int64_t)t * B + b) * ldd + col0 + cc * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += g.get(v);
+    }
+    Vec<T> ov;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) ov.set(v, acc[v]);
+    vstore<T>(dsrc + (int64_t)e * VEC, ov);
+}
+extern "C" int capmi_bcast_rows_bwd(const void* ddst, void* dsrc, int T_, int B, int H, int ldd, int col0, int dtype, void* stream) {
+    CAPMI_CHECK(ddst && dsrc, "capmi_bcast_rows_bwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_bcast_rows_bwd", {
+        CAPMI_CHECK(H % Vec<T>::N == 0 && ldd % Vec<T>::N == 0 && col0 % Vec<T>::N == 0, "capmi_bcast_rows_bwd: misaligned");
+        int cpr = H / Vec<T>::N;
+        hipLaunchKernelGGL(bcast_rows_bwd_kernel<T>, dim3(cdiv((int64_t)B * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)ddst, (T*)dsrc, T_, B, cpr, ldd, col0);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bcast_rows_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ LSTM cell (gate blocks i, f, o, g)
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_cell_fwd_kernel(const T* __restrict__ gates, const T* __restrict__ c_prev, T* h, T* c, int B, int cpr) {
+    constexpr int VEC = Vec<T>::N;
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * cpr) return;
+    int b = e / cpr, cc = e % cpr;
+    const int H = cpr * VEC;
+    const T* gr = gates + (int64_t)b * 4 * H + cc * VEC;
+    Vec<T> gi = vload<T>(gr), gf = vload<T>(gr + H), go = vload<T>(gr + 2 * H), gg = vload<T>(gr + 3 * H), cp, hv, cv;
+    if (c_prev) cp = vload<T>(c_prev + (int64_t)e * VEC);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        float i_ = sigmoidf_(gi.get(v)), f_ = sigmoidf_(gf.get(v)), o_ = sigmoidf_(go.get(v)), g_ = tanhf_(gg.get(v));
+        float cn = f_ * (c_prev ? cp.get(v) : 0.f) + i_ * g_;
+        cv.set(v, cn);
+        hv.set(v, o_ * tanhf_(cn));
+    }
+    vstore<T>(h + (int64_t)e * VEC, hv);
+    vstore<T>(c + (int64_t)e * VEC, cv);
+}
+extern "C" int capmi_lstm_cell_fwd(const void* gates, const void* c_prev, void* h, void* c, int B, int H, int dtype, void* stream) {
+    CAPMI_CHECK(gates && h && c, "capmi_lstm_cell_fwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_lstm_cell_fwd", {
+        CAPMI_CHECK(H % Vec<T>::N == 0, "capmi_lstm_cell_fwd: H not a multiple of the vector width");
+        int cpr = H / Vec<T>::N;
+        hipLaunchKernelGGL(lstm_cell_fwd_kernel<T>, dim3(cdiv((int64_t)B * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)gates, (const T*)c_prev, (T*)h, (T*)c, B, cpr);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_lstm_cell_fwd");
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const T* __restrict__ gates, const T* __restrict__ c_prev, const T* __restrict__ c,
+                                                            const T* __restrict__ dh, const T* __restrict__ dc_in, T* dgates, T* dc_prev,
+                                                            int dc_prev_acc, int B, int cpr) {
+    constexpr int VEC = Vec<T>::N;
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * cpr) return;
+    int b = e / cpr, cc = e % cpr;
+    const int H = cpr * VEC;
+    const int64_t go_ = (int64_t)b * 4 * H + cc * VEC;
+    Vec<T> gi = vload<T>(gates + go_), gf = vload<T>(gates + go_ + H), go = vload<T>(gates + go_ + 2 * H), gg = vload<T>(gates + go_ + 3 * H);
+    Vec<T> cv = vload<T>(c + (int64_t)e * VEC), dhv = vload<T>(dh + (int64_t)e * VEC), cp, dci, dcp_old;
+    if (c_prev) cp = vload<T>(c_prev + (int64_t)e * VEC);
+    if (dc_in) dci = vload<T>(dc_in + (int64_t)e * VEC);
+    if (dc_prev && dc_prev_acc) dcp_old = vload<T>(dc_prev + (int64_t)e * VEC);
+    Vec<T> di, df, do_, dg, dcp;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        float i_ = sigmoidf_(gi.get(v)), f_ = sigmoidf_(gf.get(v)), o_ = sigmoidf_(go.get(v)), g_ = tanhf_(gg.get(v));
+        float tc = tanhf_(cv.get(v));
+        float dhh = dhv.get(v);
+        float dct = (dc_in ? dci.get(v) : 0.f) + dhh * o_ * (1.f - tc * tc);
+        float cpv = c_prev ? cp.get(v) : 0.f;
+        di.set(v, dct * g_ * i_ * (1.f - i_));
+        df.set(v, dct * cpv * f_ * (1.f - f_));
+        do_.set(v, dhh * tc * o_ * (1.f - o_));
+        dg.set(v, dct * i_ * (1.f - g_ * g_));
+        float d = dct * f_;
+        if (dc_prev && dc_prev_acc) d += dcp_old.get(v);
+        dcp.set(v, d);
+    }
+    vstore<T>(dgates + go_, di);
+    vstore<T>(dgates + go_ + H, df);
+    vstore<T>(dgates + go_ + 2 * H, do_);
+    vstore<T>(dgates + go_ + 3 * H, dg);
+    if (dc_prev) vstore<T>(dc_prev + (int64_t)e * VEC, dcp);
+}
+extern "C" int capmi_lstm_cell_bwd(const void* gates, const void* c_prev, const void* c, const void* dh, const void* dc_in,
+                                   void* dgates, void* dc_prev, int dc_prev_accumulate, int B, int H, int dtype, void* stream) {
+    CAPMI_CHECK(gates && c && dh && dgates, "capmi_lstm_cell_bwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_lstm_cell_bwd", {
+        CAPMI_CHECK(H % Vec<T>::N == 0, "capmi_lstm_cell_bwd: H not a multiple of the vector width");
+        int cpr = H / Vec<T>::N;
+        hipLaunchKernelGGL(lstm_cell_bwd_kernel<T>, dim3(cdiv((int64_t)B * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)gates, (const T*)c_prev,
+                           (const T*)c, (const T*)dh, (const T*)dc_in, (T*)dgates, (T*)dc_prev, dc_prev_accumulate, B, cpr);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_lstm_cell_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ visual sentinel
+template <typename T>
+__global__ __launch_bounds__(256) void sentinel_fwd_kernel(const T* __restrict__ sgpre, const T* __restrict__ c, T* s, int64_t nchunks) {
+    constexpr int VEC = Vec<T>::N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        Vec<T> a = vload<T>(sgpre + e * VEC), cv = vload<T>(c + e * VEC), ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, sigmoidf_(a.get(v)) * tanhf_(cv.get(v)));
+        vstore<T>(s + e * VEC, ov);
+    }
+}
+extern "C" int capmi_sentinel_fwd(const void* sgpre, const void* c, void* s, int64_t n, int dtype, void* stream) {
+    CAPMI_CHECK(sgpre && c && s, "capmi_sentinel_fwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_sentinel_fwd", {
+        CAPMI_CHECK(n % Vec<T>::N == 0, "capmi_sentinel_fwd: n not a multiple of the vector width");
+        hipLaunchKernelGGL(sentinel_fwd_kernel<T>, dim3(ew_grid(n / Vec<T>::N)), dim3(256), 0, (hipStream_t)stream, (const T*)sgpre, (const T*)c, (T*)s, n / Vec<T>::N);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_sentinel_fwd");
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sentinel_bwd_kernel(const T* __restrict__ ds, const T* __restrict__ sgpre, const T* __restrict__ c,
+                                                           T* dsgpre, T* dc, int64_t nchunks) {
+    constexpr int VEC = Vec<T>::N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        Vec<T> d = vload<T>(ds + e * VEC), a = vload<T>(sgpre + e * VEC), cv = vload<T>(c + e * VEC), o1, o2;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float sg = sigmoidf_(a.get(v)), tc = tanhf_(cv.get(v)), dd = d.get(v);
+            o1.set(v, dd * tc * sg * (1.f - sg));
+            o2.set(v, dd * sg * (1.f - tc * tc));
+        }
+        vstore<T>(dsgpre + e * VEC, o1);
+        vstore<T>(dc + e * VEC, o2);
+    }
+}
+extern "C" int capmi_sentinel_bwd(const void* ds, const void* sgpre, const void* c, void* dsgpre, void* dc, int64_t n, int dtype, void* stream) {
+    CAPMI_CHECK(ds && sgpre && c && dsgpre && dc, "capmi_sentinel_bwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_sentinel_bwd", {
+        CAPMI_CHECK(n % Vec<T>::N == 0, "capmi_sentinel_bwd: n not a multiple of the vector width");
+        hipLaunchKernelGGL(sentinel_bwd_kernel<T>, dim3(ew_grid(n / Vec<T>::N)), dim3(256), 0, (hipStream_t)stream, (const T*)ds, (const T*)sgpre, (const T*)c, (T*)dsgpre, (T*)dc, n / Vec<T>::N);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_sentinel_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ adaptive attention
+// singleton mode (quirk Q1): alpha == 1, ctx = (sum_k Vt[b,k] + s)/(K+1); thread per (b, h-chunk).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_singleton_fwd_kernel(const T* __restrict__ Vt, const T* __restrict__ s, const T* __restrict__ p,
+                                                                 T* out, int T_, int B, int K, int cpr) {
+    constexpr int VEC = Vec<T>::N;
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * cpr) return;
+    int b = e / cpr, cc = e % cpr;
+    float vs[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) vs[v] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        Vec<T> x = vload<T>(Vt + (((int64_t)b * K + k) * cpr + cc) * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) vs[v] += x.get(v);
+    }
+    const float inv = 1.f / (float)(K + 1);
+    for (int t = 0; t < T_; ++t) {
+        int64_t o = (((int64_t)t * B + b) * cpr + cc) * VEC;
+        Vec<T> sv = vload<T>(s + o), pv = vload<T>(p + o), ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, (vs[v] + sv.get(v)) * inv + pv.get(v));
+        vstore<T>(out + o, ov);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void attn_singleton_bwd_kernel(const T* __restrict__ dout, T* ds, T* dVt, int T_, int B, int K, int cpr) {
+    constexpr int VEC = Vec<T>::N;
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * cpr) return;
+    int b = e / cpr, cc = e % cpr;
+    const float inv = 1.f / (float)(K + 1);
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int t = 0; t < T_; ++t) {
+        int64_t o = (((int64_t)t * B + b) * cpr + cc) * VEC;
+        Vec<T> d = vload<T>(dout + o), ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { float g = d.get(v) * inv; acc[v] += g; ov.set(v, g); }
+        vstore<T>(ds + o, ov);
+    }
+    Vec<T> ov;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) ov.set(v, acc[v]);
+    for (int k = 0; k < K; ++k) vstore<T>(dVt + (((int64_t)b * K + k) * cpr + cc) * VEC, ov);
+}
+
+// slots mode forward: one workgroup per row m = (t, b).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_slots_fwd_kernel(const T* __restrict__ Ve, const T* __restrict__ Vt, const T* __restrict__ q,
+                                                             const T* __restrict__ se, const T* __restrict__ s, const T* __restrict__ p,
+                                                             const T* __restrict__ w10, const float* __restrict__ b10, T* out, float* alpha,
+                                                             int B, int K, int H) {
+    constexpr int VEC = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [H] ctx  | [K+1] e | [16] scratch
+    float* ctx = smem;
+    float* ev = smem + H;
+    float* scratch = ev + (K + 1);
+    const int m = blockIdx.x, b = m % B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cpr = H / VEC;
+    for (int i = tid; i < H; i += 256) ctx[i] = 0.f;
+    // e_k = sum_h tanh(feat_emb[k,h] + q[h]) * w10[h] + b10  -- one wave per slot
+    for (int k = wave; k <= K; k += 4) {
+        const T* row = k < K ? Ve + ((int64_t)b * K + k) * H : se + (int64_t)m * H;
+        float part = 0.f;
+        for (int cc = lane; cc < cpr; cc += 64) {
+            Vec<T> a = vload<T>(row + cc * VEC), qq = vload<T>(q + (int64_t)m * H + cc * VEC), ww = vload<T>(w10 + cc * VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) part += tanhf_(a.get(v) + qq.get(v)) * ww.get(v);
+        }
+        part = wave_sum(part);
+        if (lane == 0) ev[k] = part + b10[0];
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int k = tid; k <= K; k += 256) mx = fmaxf(mx, ev[k]);
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int k = tid; k <= K; k += 256) sum += expf(ev[k] - mx);
+    sum = block_sum(sum, scratch);
+    __syncthreads();
+    for (int k = tid; k <= K; k += 256) {
+        float a = expf(ev[k] - mx) / sum;
+        ev[k] = a;
+        alpha[(int64_t)m * (K + 1) + k] = a;
+    }
+    __syncthreads();
+    // ctx[h] = sum_k alpha_k * ctx_all[k,h]
+    for (int idx = tid; idx < (K + 1) * cpr; idx += 256) {
+        int k = idx / cpr, cc = idx % cpr;
+        const T* row = k < K ? Vt + ((int64_t)b * K + k) * H : s + (int64_t)m * H;
+        Vec<T> x = vload<T>(row + cc * VEC);
+        float a = ev[k];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) atomicAdd(&ctx[cc * VEC + v], a * x.get(v));
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)(K + 1);
+    for (int cc = tid; cc < cpr; cc += 256) {
+        Vec<T> pv = vload<T>(p + (int64_t)m * H + cc * VEC), ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, ctx[cc * VEC + v] * inv + pv.get(v));
+        vstore<T>(out + (int64_t)m * H + cc * VEC, ov);
+    }
+}
+
+extern "C" int capmi_ada_attention_fwd(const void* Ve, const void* Vt, const void* q, const void* se, const void* s, const void* p,
+                                       const void* w10, const float* b10, void* out, float* alpha, int T_, int B, int K, int H,
+                                       int slots, int dtype, void* stream) {
+    CAPMI_CHECK(Vt && s && p && out, "capmi_ada_attention_fwd: null pointer");
+    CAPMI_CHECK(!slots || (Ve && q && se && w10 && b10 && alpha), "capmi_ada_attention_fwd: slots mode needs Ve,q,se,w10,b10,alpha");
+    CAPMI_DISPATCH(dtype, "capmi_ada_attention_fwd", {
+        CAPMI_CHECK(H % Vec<T>::N == 0, "capmi_ada_attention_fwd: H not a multiple of the vector width");
+        int cpr = H / Vec<T>::N;
+        if (!slots) {
+            hipLaunchKernelGGL(attn_singleton_fwd_kernel<T>, dim3(cdiv((int64_t)B * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)Vt, (const T*)s, (const T*)p, (T*)out, T_, B, K, cpr);
+        } else {
+            size_t sh = (size_t)(H + K + 1 + 16) * sizeof(float);
+            hipLaunchKernelGGL(attn_slots_fwd_kernel<T>, dim3(T_ * B), dim3(256), sh, (hipStream_t)stream, (const T*)Ve, (const T*)Vt, (const T*)q, (const T*)se,
+                               (const T*)s, (const T*)p, (const T*)w10, b10, (T*)out, alpha, B, K, H);
+        }
+    });
+    CAPMI_LAUNCH_CHECK("capmi_ada_attention_fwd");
+    return 0;
+}
+
+// slots backward, phase 1 (workgroup per row m): dalpha, de, ds, db10.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_slots_bwd1_kernel(const T* __restrict__ Vt, const T* __restrict__ s, const float* __restrict__ alpha,
+                                                              const T* __restrict__ dout, T* ds, float* de, float* db10, int B, int K, int H) {
+    constexpr int VEC = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [K+1] dalpha | [16] scratch
+    float* da = smem;
+    float* scratch = smem + (K + 1);
+    const int m = blockIdx.x, b = m % B;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cpr = H / VEC;
+    const float inv = 1.f / (float)(K + 1);
+    for (int k = wave; k <= K; k += 4) {
+        const T* row = k < K ? Vt + ((int64_t)b * K + k) * H : s + (int64_t)m * H;
+        float part = 0.f;
+        for (int cc = lane; cc < cpr; cc += 64) {
+            Vec<T> x = vload<T>(row + cc * VEC), d = vload<T>(dout + (int64_t)m * H + cc * VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) part += x.get(v) * d.get(v);
+        }
+        part = wave_sum(part);
+        if (lane == 0) da[k] = part * inv;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int k = tid; k <= K; k += 256) dot += alpha[(int64_t)m * (K + 1) + k] * da[k];
+    dot = block_sum(dot, scratch);
+    float dsum = 0.f;
+    for (int k = tid; k <= K; k += 256) {
+        float a = alpha[(int64_t)m * (K + 1) + k];
+        float d = a * (da[k] - dot);
+        de[(int64_t)m * (K + 1) + k] = d;
+        dsum += d;
+    }
+    dsum = block_sum(dsum, scratch);
+    if (tid == 0) atomicAdd(db10, dsum);
+    const float aK = alpha[(int64_t)m * (K + 1) + K] * inv;
+    for (int cc = tid; cc < cpr; cc += 256) {
+        Vec<T> d = vload<T>(dout + (int64_t)m * H + cc * VEC), ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, d.get(v) * aK);
+        vstore<T>(ds + (int64_t)m * H + cc * VEC, ov);
+    }
+}
+
+// slots backward, phase 2: workgroup per (b, tile of TH 16-byte chunks of h).  Threads = TH chunk
+// columns x (256/TH) slot groups; dVt/dVe accumulate over t in registers, dq/dw10 meet in LDS.
+template <typename T, int TH, int MAXK>
+__global__ __launch_bounds__(256) void attn_slots_bwd2_kernel(const T* __restrict__ Ve, const T* __restrict__ q, const T* __restrict__ se,
+                                                              const T* __restrict__ w10, const float* __restrict__ alpha, const float* __restrict__ de,
+                                                              const T* __restrict__ dout, T* dVt, T* dVe, T* dq, T* dse, float* dw10,
+                                                              int T_, int B, int K, int H) {
+    constexpr int VEC = Vec<T>::N;
+    constexpr int KG = 256 / TH;
+    __shared__ float sdq[TH * VEC], sdw[TH * VEC];
+    const int tid = threadIdx.x;
+    const int cc = tid % TH, kg = tid / TH;
+    const int tiles = (H / VEC + TH - 1) / TH;
+    const int b = blockIdx.x / tiles, chunk = (blockIdx.x % tiles) * TH + cc;
+    const bool cok = chunk * VEC < H;
+    const float inv = 1.f / (float)(K + 1);
+    float aVt[MAXK][VEC], aVe[MAXK][VEC], ve[MAXK][VEC], ww[VEC], dwl[VEC];
+    if (tid < TH * VEC) sdw[tid] = 0.f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { ww[v] = 0.f; dwl[v] = 0.f; }
+    if (cok) {
+        Vec<T> w = vload<T>(w10 + chunk * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ww[v] = w.get(v);
+    }
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        int k = kg + j * KG;
+        Vec<T> x = (cok && k < K) ? vload<T>(Ve + ((int64_t)b * K + k) * H + chunk * VEC) : vzero<T>();
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { ve[j][v] = x.get(v); aVt[j][v] = 0.f; aVe[j][v] = 0.f; }
+    }
+    for (int t = 0; t < T_; ++t) {
+        const int64_t m = (int64_t)t * B + b;
+        __syncthreads();
+        if (tid < TH * VEC) sdq[tid] = 0.f;
+        __syncthreads();
+        float dql[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dql[v] = 0.f;
+        Vec<T> dv = cok ? vload<T>(dout + m * H + chunk * VEC) : vzero<T>();
+        Vec<T> qv = cok ? vload<T>(q + m * H + chunk * VEC) : vzero<T>();
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) {
+            int k = kg + j * KG;
+            if (k < K) {
+                float a = alpha[m * (K + 1) + k] * inv, d = de[m * (K + 1) + k];
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float z = tanhf_(ve[j][v] + qv.get(v));
+                    float dz = d * ww[v] * (1.f - z * z);
+                    aVe[j][v] += dz;
+                    dql[v] += dz;
+                    dwl[v] += d * z;
+                    aVt[j][v] += dv.get(v) * a;
+                }
+            }
+        }
+        if (kg == 0 && cok) {      // sentinel slot K
+            float d = de[m * (K + 1) + K];
+            Vec<T> sv = vload<T>(se + m * H + chunk * VEC), o;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float z = tanhf_(sv.get(v) + qv.get(v));
+                float dz = d * ww[v] * (1.f - z * z);
+                o.set(v, dz);
+                dql[v] += dz;
+                dwl[v] += d * z;
+            }
+            vstore<T>(dse + m * H + chunk * VEC, o);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) atomicAdd(&sdq[cc * VEC + v], dql[v]);
+        __syncthreads();
+        if (kg == 0 && cok) {
+            Vec<T> o;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) o.set(v, sdq[cc * VEC + v]);
+            vstore<T>(dq + m * H + chunk * VEC, o);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXK; ++j) {
+        int k = kg + j * KG;
+        if (cok && k < K) {
+            Vec<T> o1, o2;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { o1.set(v, aVt[j][v]); o2.set(v, aVe[j][v]); }
+            vstore<T>(dVt + ((int64_t)b * K + k) * H + chunk * VEC, o1);
+            vstore<T>(dVe + ((int64_t)b * K + k) * H + chunk * VEC, o2);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) atomicAdd(&sdw[cc * VEC + v], dwl[v]);
+    __syncthreads();
+    if (kg == 0 && cok) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) atomicAdd(&dw10[chunk * VEC + v], sdw[cc * VEC + v]);
+    }
+}
+
+extern "C" int capmi_ada_attention_bwd(const void* Ve, const void* Vt, const void* q, const void* se, const void* s, const void* w10,
+                                       const float* alpha, const void* dout, void* ds, void* dVt, void* dVe, void* dq, void* dse,
+                                       float* dw10, float* db10, float* de, int T_, int B, int K, int H, int slots, int dtype,
+                                       void* stream) {
+    CAPMI_CHECK(dout && ds && dVt, "capmi_ada_attention_bwd: null pointer");
+    CAPMI_CHECK(!slots || (Ve && Vt && q && se && s && w10 && alpha && dVe && dq && dse && dw10 && db10 && de),
+                "capmi_ada_attention_bwd: slots mode needs every operand");
+    CAPMI_DISPATCH(dtype, "capmi_ada_attention_bwd", {
+        CAPMI_CHECK(H % Vec<T>::N == 0, "capmi_ada_attention_bwd: H not a multiple of the vector width");
+        int cpr = H / Vec<T>::N;
+        if (!slots) {
+            hipLaunchKernelGGL(attn_singleton_bwd_kernel<T>, dim3(cdiv((int64_t)B * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dout, (T*)ds, (T*)dVt, T_, B, K, cpr);
+        } else {
+            constexpr int TH = 8, MAXK = 8;
+            CAPMI_CHECK(K <= MAXK * (256 / TH), "capmi_ada_attention_bwd: K=%d above the supported %d", K, MAXK * (256 / TH));
+            size_t sh = (size_t)(K + 1 + 16) * sizeof(float);
+            hipLaunchKernelGGL(attn_slots_bwd1_kernel<T>, dim3(T_ * B), dim3(256), sh, (hipStream_t)stream, (const T*)Vt, (const T*)s, alpha, (const T*)dout, (T*)ds, de, db10, B, K, H);
+            int tiles = cdiv(cpr, TH);
+            hipLaunchKernelGGL((attn_slots_bwd2_kernel<T, TH, MAXK>), dim3(B * tiles), dim3(256), 0, (hipStream_t)stream, (const T*)Ve, (const T*)q, (const T*)se,
+                               (const T*)w10, alpha, de, (const T*)dout, (T*)dVt, (T*)dVe, (T*)dq, (T*)dse, dw10, T_, B, K, H);
+        }
+    });
+    CAPMI_LAUNCH_CHECK("capmi_ada_attention_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ masked softmax cross-entropy over f32 logits
+__global__ __launch_bounds__(256) void xent_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, float* row_loss,
+                                                       float* row_lse, int V, int ld, int padding_idx) {
+    __shared__ float scratch[16];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (int64_t)m * ld;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, row[i]);
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 256) sum += expf(row[i] - mx);
+    sum = block_sum(sum, scratch);
+    if (tid == 0) {
+        float lse = logf(sum) + mx;
+        int64_t t = target[m];
+        row_lse[m] = lse;
+        row_loss[m] = (t != padding_idx && t >= 0 && t < V) ? lse - row[t] : 0.f;
+    }
+}
+extern "C" int capmi_softmax_xent_fwd(const float* logits, const int64_t* target, float* row_loss, float* row_lse, int M, int V,
+                                      int ld, int padding_idx, void* stream) {
+    CAPMI_CHECK(logits && target && row_loss && row_lse, "capmi_softmax_xent_fwd: null pointer");
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(xent_fwd_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, target, row_loss, row_lse, V, ld, padding_idx);
+    CAPMI_LAUNCH_CHECK("capmi_softmax_xent_fwd");
+    return 0;
+}
+// loss = sum(row_loss) / count(target != pad); single workgroup, fixed summation order (deterministic)
+__global__ __launch_bounds__(1024) void xent_finalize_kernel(const float* __restrict__ row_loss, const int64_t* __restrict__ target, float* loss_out,
+                                                             float* count_out, int M, int padding_idx) {
+    __shared__ float scratch[16];
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < M; i += 1024) { s += row_loss[i]; c += target[i] != padding_idx ? 1.f : 0.f; }
+    s = block_sum(s, scratch);
+    c = block_sum(c, scratch);
+    if (threadIdx.x == 0) { loss_out[0] = s / c; count_out[0] = c; }
+}
+extern "C" int capmi_xent_finalize(const float* row_loss, const int64_t* target, float* loss_out, float* count_out, int M,
+                                   int padding_idx, void* stream) {
+    CAPMI_CHECK(row_loss && target && loss_out && count_out, "capmi_xent_finalize: null pointer");
+    hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, target, loss_out, count_out, M, padding_idx);
+    CAPMI_LAUNCH_CHECK("capmi_xent_finalize");
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void xent_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ target, const float* __restrict__ row_lse,
+                                                       const float* __restrict__ count, T* dlogits, int V, int ld, int ldd, int padding_idx) {
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (int64_t)m * ld;
+    T* drow = dlogits + (int64_t)m * ldd;
+    const int64_t t = target[m];
+    const bool live = t != padding_idx && t >= 0 && t < V;
+    const float scale = live ? 1.f / count[0] : 0.f;
+    const float lse = row_lse[m];
+    for (int i = tid; i < ldd; i += 256) {
+        float g = 0.f;
+        if (i < V && live) g = (expf(row[i] - lse) - (i == t ? 1.f : 0.f)) * scale;
+        drow[i] = from_f32<T>(g);
+    }
+}
+extern "C" int capmi_softmax_xent_bwd(const float* logits, const int64_t* target, const float* row_lse, const float* count,
+                                      void* dlogits, int M, int V, int ld, int ldd, int padding_idx, int dtype, void* stream) {
+    CAPMI_CHECK(logits && target && row_lse && count && dlogits, "capmi_softmax_xent_bwd: null pointer");
+    if (M <= 0) return 0;
+    CAPMI_DISPATCH(dtype, "capmi_softmax_xent_bwd", {
+        hipLaunchKernelGGL(xent_bwd_kernel<T>, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, target, row_lse, count, (T*)dlogits, V, ld, ldd, padding_idx);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_softmax_xent_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ argmax (lowest index on ties)
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int64_t* ids, float* ids_f32, int ld_f32, int V, int ld) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (int64_t)m * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+        float f = row[i];
+        if (f > best || (f == best && i < bi)) { best = f; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float ob = __shfl_xor(best, o, 64);
+        int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        if (bi == 0x7fffffff) bi = 0;
+        ids[m] = bi;
+        if (ids_f32) ids_f32[(int64_t)m * ld_f32] = (float)bi;
+    }
+}
+extern "C" int capmi_argmax(const float* logits, int64_t* ids_out, float* ids_f32, int ld_f32, int M, int V, int ld, void* stream) {
+    CAPMI_CHECK(logits && ids_out, "capmi_argmax: null pointer");
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(argmax_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, ids_out, ids_f32, ld_f32, V, ld);
+    CAPMI_LAUNCH_CHECK("capmi_argmax");
+    return 0;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, int M, int N, int lda, float* out, ColLayout L) {
+    constexpr int VEC = Vec<T>::N;
+    __shared__ float s1[256 * VEC];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L.cpc * VEC; i += 256) s1[i] = 0.f;
+    __syncthreads();
+    const int cc = tid % L.cpc, rr = tid / L.cpc;
+    const int chunk = blockIdx.y * L.cpc + cc;
+    if (rr < L.rp && chunk * VEC < N) {
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        const int m_begin = blockIdx.x * L.rows_per_block;
+        const int m_end = min(M, m_begin + L.rows_per_block);
+        for (int m = m_begin + rr; m < m_end; m += L.rp) {
+            Vec<T> x = vload<T>(a + (int64_t)m * lda + chunk * VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += x.get(v);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) atomicAdd(&s1[cc * VEC + v], acc[v]);
+    }
+    __syncthreads();
+    for (int i = tid; i < L.cpc * VEC; i += 256) {
+        int c = blockIdx.y * L.cpc * VEC + i;
+        if (c < N) atomicAdd(&out[c], s1[i]);
+    }
+}
+extern "C" int capmi_colsum(const void* a, int M, int N, int lda, float* out, int dtype, void* stream) {
+    CAPMI_CHECK(a && out, "capmi_colsum: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_colsum", {
+        constexpr int VEC = Vec<T>::N;
+        CAPMI_CHECK(lda % VEC == 0 && lda >= (N + VEC - 1) / VEC * VEC, "capmi_colsum: lda=%d must be a multiple of %d covering N=%d", lda, VEC, N);
+        int gx, gy;
+        ColLayout L = col_layout(M, (N + VEC - 1) / VEC * VEC, VEC, &gx, &gy);
+        hipLaunchKernelGGL(colsum_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)a, M, N, lda, out, L);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_colsum");
+    return 0;
+}

@@ -1,0 +1,631 @@
+// HBM-bound encoder kernels for gfx950: batch-norm (statistics, apply, backward), depthwise 3x3,
+// 3x3/s2 max pool, stem im2col and the elementwise glue.  All operate on NHWC tensors viewed as
+// [M = B*H*W][C]; every global access is a 16-byte chunk (8 bf16 / 4 f32) of consecutive
+// channels, so a 64-lane wave touches 1 KiB of contiguous memory per instruction.
+#include "common.h"
+
+// ------------------------------------------------------------------ BN statistics
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int M, int C, float* stats, ColLayout L) {
+    constexpr int VEC = Vec<T>::N;
+    __shared__ float s1[256 * VEC], s2[256 * VEC];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L.cpc * VEC; i += 256) { s1[i] = 0.f; s2[i] = 0.f; }
+    __syncthreads();
+    const int cc = tid % L.cpc, rr = tid / L.cpc;
+    const int chunk = blockIdx.y * L.cpc + cc;
+    const bool active = rr < L.rp && chunk * VEC < C;
+    float a1[VEC], a2[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { a1[v] = 0.f; a2[v] = 0.f; }
+    if (active) {
+        const int m_begin = blockIdx.x * L.rows_per_block;
+        const int m_end = min(M, m_begin + L.rows_per_block);
+        for (int m = m_begin + rr; m < m_end; m += L.rp) {
+            Vec<T> xv = vload<T>(x + (int64_t)m * C + chunk * VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { float f = xv.get(v); a1[v] += f; a2[v] += f * f; }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { atomicAdd(&s1[cc * VEC + v], a1[v]); atomicAdd(&s2[cc * VEC + v], a2[v]); }
+    }
+    __syncthreads();
+    for (int i = tid; i < L.cpc * VEC; i += 256) {
+        int c = blockIdx.y * L.cpc * VEC + i;
+        if (c < C) { atomicAdd(&stats[c], s1[i]); atomicAdd(&stats[C + c], s2[i]); }
+    }
+}
+
+extern "C" int capmi_bn_stats(const void* x, int M, int C, float* stats, int dtype, void* stream) {
+    CAPMI_CHECK(x && stats, "capmi_bn_stats: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_bn_stats", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_stats: C=%d not a multiple of %d", C, Vec<T>::N);
+        int gx, gy;
+        ColLayout L = col_layout(M, C, Vec<T>::N, &gx, &gy);
+        hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, M, C, stats, L);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bn_stats");
+    return 0;
+}
+
+__global__ void bn_finalize_kernel(const float* stats, int M, int C, const float* scale, const float* offset,
+                                   float* run_mean, float* run_var, float momentum, float eps,
+                                   float* saved_mean, float* saved_invstd, float* coef_a, float* coef_b,
+                                   int update_running) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    // f64 for the E[x^2]-E[x]^2 cancellation; per-channel work is negligible
+    double mean = (double)stats[c] / M;
+    double var = (double)stats[C + c] / M - mean * mean;
+    if (var < 0) var = 0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    saved_mean[c] = (float)mean;
+    saved_invstd[c] = invstd;
+    float a = scale[c] * invstd;
+    coef_a[c] = a;
+    coef_b[c] = offset[c] - (float)mean * a;
+    if (update_running) {
+        run_mean[c] = run_mean[c] * momentum + (float)mean * (1.f - momentum);
+        run_var[c] = run_var[c] * momentum + (float)var * (1.f - momentum);
+    }
+}
+
+extern "C" int capmi_bn_finalize(const float* stats, int M, int C, const float* scale, const float* offset,
+                                 float* run_mean, float* run_var, float momentum, float eps,
+                                 float* saved_mean, float* saved_invstd, float* coef_a, float* coef_b,
+                                 int update_running, void* stream) {
+    CAPMI_CHECK(stats && scale && offset && saved_mean && saved_invstd && coef_a && coef_b, "capmi_bn_finalize: null pointer");
+    CAPMI_CHECK(!update_running || (run_mean && run_var), "capmi_bn_finalize: running stats missing");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, M, C, scale,
+                       offset, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, coef_b, update_running);
+    CAPMI_LAUNCH_CHECK("capmi_bn_finalize");
+    return 0;
+}
+
+// ------------------------------------------------------------------ BN apply (+residual, +act)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ ca,
+                                                       const float* __restrict__ cb, const T* __restrict__ res,
+                                                       T* __restrict__ y, int64_t nchunks, int cpr, int act) {
+    constexpr int VEC = Vec<T>::N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        int c0 = (int)(e % cpr) * VEC;
+        Vec<T> xv = vload<T>(x + e * VEC), rv, ov;
+        if (res) rv = vload<T>(res + e * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float f = ca[c0 + v] * xv.get(v) + cb[c0 + v];
+            if (res) f += rv.get(v);
+            ov.set(v, apply_act(f, act));
+        }
+        vstore<T>(y + e * VEC, ov);
+    }
+}
+
+extern "C" int capmi_bn_apply(const void* x, const float* coef_a, const float* coef_b, const void* res, void* y,
+                              int M, int C, int act, int dtype, void* stream) {
+    CAPMI_CHECK(x && coef_a && coef_b && y, "capmi_bn_apply: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_bn_apply", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_apply: C=%d not a multiple of %d", C, Vec<T>::N);
+        int64_t n = (int64_t)M * C / Vec<T>::N;
+        hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, coef_a,
+                           coef_b, (const T*)res, (T*)y, n, C / Vec<T>::N, act);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bn_apply");
+    return 0;
+}
+
+// ------------------------------------------------------------------ BN backward
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const T* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* red, int M, int C,
+                                                            int act, ColLayout L) {
+    constexpr int VEC = Vec<T>::N;
+    __shared__ float s1[256 * VEC], s2[256 * VEC];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < L.cpc * VEC; i += 256) { s1[i] = 0.f; s2[i] = 0.f; }
+    __syncthreads();
+    const int cc = tid % L.cpc, rr = tid / L.cpc;
+    const int chunk = blockIdx.y * L.cpc + cc;
+    const bool active = rr < L.rp && chunk * VEC < C;
+    if (active) {
+        float a1[VEC], a2[VEC], mu[VEC], is[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { a1[v] = 0.f; a2[v] = 0.f; mu[v] = mean[chunk * VEC + v]; is[v] = invstd[chunk * VEC + v]; }
+        const int m_begin = blockIdx.x * L.rows_per_block;
+        const int m_end = min(M, m_begin + L.rows_per_block);
+        for (int m = m_begin + rr; m < m_end; m += L.rp) {
+            const int64_t off = (int64_t)m * C + chunk * VEC;
+            Vec<T> dv = vload<T>(dy + off), xv = vload<T>(x + off), yv;
+            if (act) yv = vload<T>(y + off);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                float dz = dv.get(v);
+                if (act) dz *= act_grad_from_out(yv.get(v), act);
+                a1[v] += dz;
+                a2[v] += dz * (xv.get(v) - mu[v]) * is[v];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { atomicAdd(&s1[cc * VEC + v], a1[v]); atomicAdd(&s2[cc * VEC + v], a2[v]); }
+    }
+    __syncthreads();
+    for (int i = tid; i < L.cpc * VEC; i += 256) {
+        int c = blockIdx.y * L.cpc * VEC + i;
+        if (c < C) { atomicAdd(&red[c], s1[i]); atomicAdd(&red[C + c], s2[i]); }
+    }
+}
+
+extern "C" int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y, const float* saved_mean,
+                                   const float* saved_invstd, float* red, int M, int C, int act, int dtype,
+                                   void* stream) {
+    CAPMI_CHECK(dy && x && saved_mean && saved_invstd && red, "capmi_bn_bwd_reduce: null pointer");
+    CAPMI_CHECK(!act || y, "capmi_bn_bwd_reduce: activation mask needs y");
+    CAPMI_DISPATCH(dtype, "capmi_bn_bwd_reduce", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_bwd_reduce: C=%d not a multiple of %d", C, Vec<T>::N);
+        int gx, gy;
+        ColLayout L = col_layout(M, C, Vec<T>::N, &gx, &gy);
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+                           (const T*)x, (const T*)y, saved_mean, saved_invstd, red, M, C, act, L);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bn_bwd_reduce");
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const T* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ red, T* dx, int dx_acc, T* dres,
+                                                           int dres_acc, int64_t nchunks, int cpr, int C, float inv_m, int act) {
+    constexpr int VEC = Vec<T>::N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(e % cpr) * VEC;
+        Vec<T> dv = vload<T>(dy + e * VEC), xv = vload<T>(x + e * VEC), yv, ov, rv, dxo, dro;
+        if (act) yv = vload<T>(y + e * VEC);
+        if (dx_acc) dxo = vload<T>(dx + e * VEC);
+        if (dres && dres_acc) dro = vload<T>(dres + e * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            const int c = c0 + v;
+            float dz = dv.get(v);
+            if (act) dz *= act_grad_from_out(yv.get(v), act);
+            float xhat = (xv.get(v) - mean[c]) * invstd[c];
+            float g = scale[c] * invstd[c] * (dz - red[c] * inv_m - xhat * red[C + c] * inv_m);
+            if (dx_acc) g += dxo.get(v);
+            ov.set(v, g);
+            if (dres) rv.set(v, dres_acc ? dz + dro.get(v) : dz);
+        }
+        vstore<T>(dx + e * VEC, ov);
+        if (dres) vstore<T>(dres + e * VEC, rv);
+    }
+}
+
+extern "C" int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, const float* saved_mean,
+                                  const float* saved_invstd, const float* scale, const float* red, void* dx,
+                                  int dx_accumulate, void* dres, int dres_accumulate, int M, int C, int act, int dtype,
+                                  void* stream) {
+    CAPMI_CHECK(dy && x && saved_mean && saved_invstd && scale && red && dx, "capmi_bn_bwd_apply: null pointer");
+    CAPMI_CHECK(!act || y, "capmi_bn_bwd_apply: activation mask needs y");
+    CAPMI_DISPATCH(dtype, "capmi_bn_bwd_apply", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_bwd_apply: C=%d not a multiple of %d", C, Vec<T>::N);
+        int64_t n = (int64_t)M * C / Vec<T>::N;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
+                           (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, red, (T*)dx, dx_accumulate,
+                           (T*)dres, dres_accumulate, n, C / Vec<T>::N, C, 1.f / (float)M, act);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bn_bwd_apply");
+    return 0;
+}
+
+// ------------------------------------------------------------------ elementwise glue
+template <typename T>
+__global__ __launch_bounds__(256) void add_act_kernel(const T* __restrict__ a, const T* __restrict__ b, T* y, int64_t nchunks, int act) {
+    constexpr int VEC = Vec<T>::N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        Vec<T> av = vload<T>(a + e * VEC), bv = vload<T>(b + e * VEC), ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, apply_act(av.get(v) + bv.get(v), act));
+        vstore<T>(y + e * VEC, ov);
+    }
+}
+extern "C" int capmi_add_act(const void* a, const void* b, void* y, int64_t n, int act, int dtype, void* stream) {
+    CAPMI_CHECK(a && b && y, "capmi_add_act: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_add_act", {
+        CAPMI_CHECK(n % Vec<T>::N == 0, "capmi_add_act: n not a multiple of the vector width");
+        int64_t nc = n / Vec<T>::N;
+        hipLaunchKernelGGL(add_act_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, (T*)y, nc, act);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_add_act");
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* dx, int acc, int64_t nchunks, int act) {
+    constexpr int VEC = Vec<T>::N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        Vec<T> dv = vload<T>(dy + e * VEC), yv, ov, old;
+        if (act) yv = vload<T>(y + e * VEC);
+        if (acc) old = vload<T>(dx + e * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float g = dv.get(v);
+            if (act) g *= act_grad_from_out(yv.get(v), act);
+            if (acc) g += old.get(v);
+            ov.set(v, g);
+        }
+        vstore<T>(dx + e * VEC, ov);
+    }
+}
+extern "C" int capmi_act_bwd(const void* dy, const void* y, void* dx, int accumulate, int64_t n, int act, int dtype, void* stream) {
+    CAPMI_CHECK(dy && dx && (!act || y), "capmi_act_bwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_act_bwd", {
+        CAPMI_CHECK(n % Vec<T>::N == 0, "capmi_act_bwd: n not a multiple of the vector width");
+        int64_t nc = n / Vec<T>::N;
+        hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_grid(nc)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)y, (T*)dx, accumulate, nc, act);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_act_bwd");
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mean_rows_kernel(const T* __restrict__ x, T* out, int B, int K, int cpr) {
+    constexpr int VEC = Vec<T>::N;
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= B * cpr) return;
+    int b = e / cpr, cc = e % cpr;
+    float acc[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        Vec<T> xv = vload<T>(x + ((int64_t)(b * K + k) * cpr + cc) * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] += xv.get(v);
+    }
+    Vec<T> ov;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) ov.set(v, acc[v] / (float)K);
+    vstore<T>(out + (int64_t)e * VEC, ov);
+}
+extern "C" int capmi_mean_rows(const void* x, void* out, int B, int K, int C, int dtype, void* stream) {
+    CAPMI_CHECK(x && out, "capmi_mean_rows: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_mean_rows", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_mean_rows: C not a multiple of the vector width");
+        int cpr = C / Vec<T>::N;
+        hipLaunchKernelGGL(mean_rows_kernel<T>, dim3(cdiv((int64_t)B * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)out, B, K, cpr);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_mean_rows");
+    return 0;
+}
+// dx[b][k][:] += dout[b][:] / K
+template <typename T>
+__global__ __launch_bounds__(256) void mean_rows_bwd_kernel(const T* __restrict__ dout, T* dx, int64_t nchunks, int K, int cpr) {
+    constexpr int VEC = Vec<T>::N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        int cc = (int)(e % cpr);
+        int64_t b = e / cpr / K;
+        Vec<T> g = vload<T>(dout + (b * cpr + cc) * VEC), old = vload<T>(dx + e * VEC), ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, old.get(v) + g.get(v) / (float)K);
+        vstore<T>(dx + e * VEC, ov);
+    }
+}
+extern "C" int capmi_mean_rows_bwd(const void* dout, void* dx, int B, int K, int C, int dtype, void* stream) {
+    CAPMI_CHECK(dout && dx, "capmi_mean_rows_bwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_mean_rows_bwd", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_mean_rows_bwd: C not a multiple of the vector width");
+        int cpr = C / Vec<T>::N;
+        int64_t n = (int64_t)B * K * cpr;
+        hipLaunchKernelGGL(mean_rows_bwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)dout, (T*)dx, n, K, cpr);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_mean_rows_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------------ stem im2col (NCHW f32 feed -> patch matrix)
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_stem_kernel(const float* __restrict__ img, T* out, int B, int C, int H, int W,
+                                                          int ks, int stride, int pad, int Ho, int Wo, int Kpad) {
+    constexpr int VEC = Vec<T>::N;
+    const int cpr = Kpad / VEC;
+    const int64_t nchunks = (int64_t)B * Ho * Wo * cpr;
+    const int K = ks * ks * C;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        int kc = (int)(e % cpr);
+        int64_t m = e / cpr;
+        int wo = (int)(m % Wo);
+        int ho = (int)((m / Wo) % Ho);
+        int b = (int)(m / ((int64_t)Wo * Ho));
+        Vec<T> ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            int k = kc * VEC + v;
+            float f = 0.f;
+            if (k < K) {
+                int c = k % C, tap = k / C;
+                int r = tap / ks, q = tap % ks;
+                int hi = ho * stride - pad + r, wi = wo * stride - pad + q;
+                if (hi >= 0 && hi < H && wi >= 0 && wi < W) f = img[(((int64_t)b * C + c) * H + hi) * W + wi];
+            }
+            ov.set(v, f);
+        }
+        vstore<T>(out + e * VEC, ov);
+    }
+}
+extern "C" int capmi_im2col_stem(const float* img, void* out, int B, int C, int H, int W, int k, int stride, int pad,
+                                 int Ho, int Wo, int Kpad, int dtype, void* stream) {
+    CAPMI_CHECK(img && out, "capmi_im2col_stem: null pointer");
+    CAPMI_CHECK(Kpad >= k * k * C, "capmi_im2col_stem: Kpad too small");
+    CAPMI_DISPATCH(dtype, "capmi_im2col_stem", {
+        CAPMI_CHECK(Kpad % Vec<T>::N == 0, "capmi_im2col_stem: Kpad not a multiple of the vector width");
+        int64_t n = (int64_t)B * Ho * Wo * (Kpad / Vec<T>::N);
+        hipLaunchKernelGGL(im2col_stem_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, img, (T*)out, B, C, H, W, k, stride, pad, Ho, Wo, Kpad);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_im2col_stem");
+    return 0;
+}
+
+// ------------------------------------------------------------------ depthwise 3x3
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w, T* y, int B, int Hi, int Wi,
+                                                         int cpr, int stride, int Ho, int Wo) {
+    constexpr int VEC = Vec<T>::N;
+    const int64_t nchunks = (int64_t)B * Ho * Wo * cpr;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        int cc = (int)(e % cpr);
+        int64_t m = e / cpr;
+        int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho);
+        int64_t b = m / ((int64_t)Wo * Ho);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int hi = ho * stride - 1 + r;
+            if (hi < 0 || hi >= Hi) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                int wi = wo * stride - 1 + q;
+                if (wi < 0 || wi >= Wi) continue;
+                Vec<T> xv = vload<T>(x + (((b * Hi + hi) * Wi + wi) * cpr + cc) * VEC);
+                Vec<T> wv = vload<T>(w + ((int64_t)(r * 3 + q) * cpr + cc) * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += xv.get(v) * wv.get(v);
+            }
+        }
+        Vec<T> ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, acc[v]);
+        vstore<T>(y + e * VEC, ov);
+    }
+}
+extern "C" int capmi_dwconv3x3_fwd(const void* x, const void* w, void* y, int B, int Hi, int Wi, int C, int stride, int Ho,
+                                   int Wo, int dtype, void* stream) {
+    CAPMI_CHECK(x && w && y, "capmi_dwconv3x3_fwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_dwconv3x3_fwd", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_dwconv3x3_fwd: C not a multiple of the vector width");
+        int cpr = C / Vec<T>::N;
+        int64_t n = (int64_t)B * Ho * Wo * cpr;
+        hipLaunchKernelGGL(dwconv_fwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)w, (T*)y, B, Hi, Wi, cpr, stride, Ho, Wo);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_dwconv3x3_fwd");
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const T* __restrict__ dy, const T* __restrict__ w, T* dx, int B, int Hi, int Wi,
+                                                              int cpr, int stride, int Ho, int Wo, int acc_flag) {
+    constexpr int VEC = Vec<T>::N;
+    const int64_t nchunks = (int64_t)B * Hi * Wi * cpr;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        int cc = (int)(e % cpr);
+        int64_t m = e / cpr;
+        int wi = (int)(m % Wi), hi = (int)((m / Wi) % Hi);
+        int64_t b = m / ((int64_t)Wi * Hi);
+        float acc[VEC];
+        if (acc_flag) {
+            Vec<T> old = vload<T>(dx + e * VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = old.get(v);
+        } else {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int hn = hi + 1 - r;
+            if (hn < 0 || hn % stride) continue;
+            int ho = hn / stride;
+            if (ho >= Ho) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                int wn = wi + 1 - q;
+                if (wn < 0 || wn % stride) continue;
+                int wo = wn / stride;
+                if (wo >= Wo) continue;
+                Vec<T> dv = vload<T>(dy + (((b * Ho + ho) * Wo + wo) * cpr + cc) * VEC);
+                Vec<T> wv = vload<T>(w + ((int64_t)(r * 3 + q) * cpr + cc) * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += dv.get(v) * wv.get(v);
+            }
+        }
+        Vec<T> ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, acc[v]);
+        vstore<T>(dx + e * VEC, ov);
+    }
+}
+extern "C" int capmi_dwconv3x3_bwd_data(const void* dy, const void* w, void* dx, int B, int Hi, int Wi, int C, int stride,
+                                        int Ho, int Wo, int accumulate, int dtype, void* stream) {
+    CAPMI_CHECK(dy && w && dx, "capmi_dwconv3x3_bwd_data: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_dwconv3x3_bwd_data", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_dwconv3x3_bwd_data: C not a multiple of the vector width");
+        int cpr = C / Vec<T>::N;
+        int64_t n = (int64_t)B * Hi * Wi * cpr;
+        hipLaunchKernelGGL(dwconv_bwd_data_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)w, (T*)dx, B, Hi, Wi, cpr, stride, Ho, Wo, accumulate);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_dwconv3x3_bwd_data");
+    return 0;
+}
+
+// dw[r][q][c] += sum over output pixels dy[p][c] * x[p*stride + tap][c]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* dw, int B, int Hi, int Wi,
+                                                                int C, int stride, int Ho, int Wo, ColLayout L) {
+    constexpr int VEC = Vec<T>::N;
+    __shared__ float sacc[9 * 64 * VEC];      // col_layout(max_cpc = 64)
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 9 * L.cpc * VEC; i += 256) sacc[i] = 0.f;
+    __syncthreads();
+    const int cpr = C / VEC;
+    const int cc = tid % L.cpc, rr = tid / L.cpc;
+    const int chunk = blockIdx.y * L.cpc + cc;
+    const bool active = rr < L.rp && chunk < cpr;
+    if (active) {
+        float acc[9][VEC];
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[t][v] = 0.f;
+        const int M = B * Ho * Wo;
+        const int m_begin = blockIdx.x * L.rows_per_block;
+        const int m_end = min(M, m_begin + L.rows_per_block);
+        for (int m = m_begin + rr; m < m_end; m += L.rp) {
+            int wo = m % Wo, ho = (m / Wo) % Ho;
+            int64_t b = m / (Wo * Ho);
+            Vec<T> dv = vload<T>(dy + ((int64_t)m * cpr + chunk) * VEC);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                int hi = ho * stride - 1 + r;
+                if (hi < 0 || hi >= Hi) continue;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    int wi = wo * stride - 1 + q;
+                    if (wi < 0 || wi >= Wi) continue;
+                    Vec<T> xv = vload<T>(x + (((b * Hi + hi) * Wi + wi) * cpr + chunk) * VEC);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) acc[r * 3 + q][v] += dv.get(v) * xv.get(v);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) atomicAdd(&sacc[(t * L.cpc + cc) * VEC + v], acc[t][v]);
+    }
+    __syncthreads();
+    for (int i = tid; i < 9 * L.cpc * VEC; i += 256) {
+        int t = i / (L.cpc * VEC), j = i % (L.cpc * VEC);
+        int c = blockIdx.y * L.cpc * VEC + j;
+        if (c < C) atomicAdd(&dw[t * C + c], sacc[i]);
+    }
+}
+extern "C" int capmi_dwconv3x3_bwd_weight(const void* x, const void* dy, float* dw, int B, int Hi, int Wi, int C, int stride,
+                                          int Ho, int Wo, int dtype, void* stream) {
+    CAPMI_CHECK(x && dy && dw, "capmi_dwconv3x3_bwd_weight: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_dwconv3x3_bwd_weight", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_dwconv3x3_bwd_weight: C not a multiple of the vector width");
+        int gx, gy;
+        ColLayout L = col_layout(B * Ho * Wo, C, Vec<T>::N, &gx, &gy, 64);
+        hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, B, Hi, Wi, C, stride, Ho, Wo, L);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_dwconv3x3_bwd_weight");
+    return 0;
+}
+
+// ------------------------------------------------------------------ 3x3 stride-2 pad-1 max pool
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* y, uint8_t* idx, int B, int Hi, int Wi, int cpr, int Ho, int Wo) {
+    constexpr int VEC = Vec<T>::N;
+    const int64_t nchunks = (int64_t)B * Ho * Wo * cpr;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        int cc = (int)(e % cpr);
+        int64_t m = e / cpr;
+        int wo = (int)(m % Wo), ho = (int)((m / Wo) % Ho);
+        int64_t b = m / ((int64_t)Wo * Ho);
+        float best[VEC];
+        int bi[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { best[v] = -INFINITY; bi[v] = 0; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            int hi = ho * 2 - 1 + r;
+            if (hi < 0 || hi >= Hi) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                int wi = wo * 2 - 1 + q;
+                if (wi < 0 || wi >= Wi) continue;
+                Vec<T> xv = vload<T>(x + (((b * Hi + hi) * Wi + wi) * cpr + cc) * VEC);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    float f = xv.get(v);
+                    if (f > best[v]) { best[v] = f; bi[v] = r * 3 + q; }   // first maximum wins ties
+                }
+            }
+        }
+        Vec<T> ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { ov.set(v, best[v]); idx[e * VEC + v] = (uint8_t)bi[v]; }
+        vstore<T>(y + e * VEC, ov);
+    }
+}
+extern "C" int capmi_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                      int dtype, void* stream) {
+    CAPMI_CHECK(x && y && idx, "capmi_maxpool3x3s2_fwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_maxpool3x3s2_fwd", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_maxpool3x3s2_fwd: C not a multiple of the vector width");
+        int cpr = C / Vec<T>::N;
+        int64_t n = (int64_t)B * Ho * Wo * cpr;
+        hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, idx, B, Hi, Wi, cpr, Ho, Wo);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_maxpool3x3s2_fwd");
+    return 0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* dx, int B, int Hi, int Wi, int cpr, int Ho, int Wo) {
+    constexpr int VEC = Vec<T>::N;
+    const int64_t nchunks = (int64_t)B * Hi * Wi * cpr;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
+        int cc = (int)(e % cpr);
+        int64_t m = e / cpr;
+        int wi = (int)(m % Wi), hi = (int)((m / Wi) % Hi);
+        int64_t b = m / ((int64_t)Wi * Hi);
+        float acc[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        for (int r = 0; r < 3; ++r) {
+            int hn = hi + 1 - r;
+            if (hn < 0 || (hn & 1)) continue;
+            int ho = hn >> 1;
+            if (ho >= Ho) continue;
+            for (int q = 0; q < 3; ++q) {
+                int wn = wi + 1 - q;
+                if (wn < 0 || (wn & 1)) continue;
+                int wo = wn >> 1;
+                if (wo >= Wo) continue;
+                int64_t o = (((b * Ho + ho) * Wo + wo) * cpr + cc) * VEC;
+                Vec<T> dv = vload<T>(dy + o);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if (idx[o + v] == r * 3 + q) acc[v] += dv.get(v);
+            }
+        }
+        Vec<T> ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, acc[v]);
+        vstore<T>(dx + e * VEC, ov);
+    }
+}
+extern "C" int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                      int dtype, void* stream) {
+    CAPMI_CHECK(dy && idx && dx, "capmi_maxpool3x3s2_bwd: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_maxpool3x3s2_bwd", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_maxpool3x3s2_bwd: C not a multiple of the vector width");
+        int cpr = C / Vec<T>::N;
+        int64_t n = (int64_t)B * Hi * Wi * cpr;
+        hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, idx, (T*)dx, B, Hi, Wi, cpr, Ho, Wo);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_maxpool3x3s2_bwd");
+    return 0;
+}

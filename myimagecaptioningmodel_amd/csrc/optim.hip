@@ -1,0 +1,89 @@
+// Optimizer + weight-shadow kernels: Paddle-1.8 Adam over one flat f32 range, f32->bf16 casts,
+// and the data-gradient weight form ([N][kh][kw][C] -> [C][kh][kw][N], taps flipped).
+#include "common.h"
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n, float lr_t, float b1, float b2, float eps, float clip, float gscale) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float gg = gv[k] * gscale;
+            if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
+            mv[k] = b1 * mv[k] + (1.f - b1) * gg;
+            vv[k] = b2 * vv[k] + (1.f - b2) * gg * gg;
+            pv[k] = pv[k] - lr_t * (mv[k] / (sqrtf(vv[k]) + eps));
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        int64_t i = n4 * 4 + threadIdx.x;
+        float gg = g[i] * gscale;
+        if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
+        float mm = b1 * m[i] + (1.f - b1) * gg, vv = b2 * v[i] + (1.f - b2) * gg * gg;
+        m[i] = mm; v[i] = vv;
+        p[i] = p[i] - lr_t * (mm / (sqrtf(vv) + eps));
+    }
+}
+extern "C" int capmi_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2, float eps,
+                          float clip, float grad_scale, void* stream) {
+    CAPMI_CHECK(p && g && m && v, "capmi_adam: null pointer");
+    CAPMI_CHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "capmi_adam: buffers must be 16-byte aligned");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, b1, b2, eps, clip, grad_scale);
+    CAPMI_LAUNCH_CHECK("capmi_adam");
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = from_f32<T>(src[i]);
+}
+extern "C" int capmi_cast(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+    CAPMI_CHECK(src && dst, "capmi_cast: null pointer");
+    if (n <= 0) return 0;
+    CAPMI_DISPATCH(dtype, "capmi_cast", {
+        hipLaunchKernelGGL(cast_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, n);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_cast");
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dgrad_form_kernel(const float* __restrict__ w, T* wt, int N, int kh, int kw, int C, int ldt) {
+    const int64_t total = (int64_t)C * kh * kw * ldt;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        int n = (int)(i % ldt);
+        int64_t rest = i / ldt;
+        int q = (int)(rest % kw);
+        int r = (int)((rest / kw) % kh);
+        int c = (int)(rest / ((int64_t)kw * kh));
+        float f = 0.f;
+        if (n < N) f = w[(((int64_t)n * kh + (kh - 1 - r)) * kw + (kw - 1 - q)) * C + c];
+        wt[i] = from_f32<T>(f);
+    }
+}
+extern "C" int capmi_weight_dgrad_form(const float* w, void* wt, int N, int kh, int kw, int C, int ldt, int dtype, void* stream) {
+    CAPMI_CHECK(w && wt, "capmi_weight_dgrad_form: null pointer");
+    CAPMI_CHECK(ldt >= N && (ldt == N || kh * kw == 1), "capmi_weight_dgrad_form: padded rows only for 1x1 weights");
+    CAPMI_DISPATCH(dtype, "capmi_weight_dgrad_form", {
+        hipLaunchKernelGGL(dgrad_form_kernel<T>, dim3(ew_grid((int64_t)C * kh * kw * ldt)), dim3(256), 0, (hipStream_t)stream, w, (T*)wt, N, kh, kw, C, ldt);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_weight_dgrad_form");
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, float value, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = value;
+}
+extern "C" int capmi_fill_f32(float* p, float value, int64_t n, void* stream) {
+    CAPMI_CHECK(p, "capmi_fill_f32: null pointer");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, value, n);
+    CAPMI_LAUNCH_CHECK("capmi_fill_f32");
+    return 0;
+}

@@ -1,0 +1,296 @@
+"""Decoder executor: bridge + adaptive-attention LSTM decoder + tied vocabulary projection +
+masked cross-entropy, forward and backward, plus the greedy decode loop -- as launch plans.
+
+Semantics follow /root/reference/ImageCaptioning/model/model_adaAttention_aic.py:
+  `_img2feature` :191-199, `Decoder.call` :50-135, `weight_tying_fc` :15-25,
+  `training_network` :161-183, `loss` :205-212, `eval_network` :185-189.
+
+MI355X-first restructuring (same arithmetic, different schedule): in train mode the only
+recurrence is the LSTM (x_t depends on the given caption and the image only), so every
+projection except h_{t-1}.W_h runs ONCE over all T steps as an M = T*B row GEMM; rows are
+time-major (m = t*B + b) so a timestep is a contiguous row block.  Per step only the
+[B,H]x[H,4H] recurrent GEMM (accumulated onto the precomputed input gates in its epilogue)
+and the pointwise cell remain.  BPTT mirrors it.
+"""
+import torch
+
+from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, Plan, gemm_geom
+from .params import FC
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def vocab_ld(V):
+    return (V + 7) // 8 * 8
+
+
+class DecoderRunner:
+    def __init__(self, store, B, K, T, dtype_code, torch_dtype, slots, need_backward=True):
+        cfg = store.cfg
+        self.store = store
+        self.B, self.K, self.T = B, K, T
+        self.C, self.H, self.E, self.V = store.enc.channels, cfg['hidden'], cfg['embed'], cfg['vocab']
+        self.Vld = vocab_ld(self.V)
+        self.code, self.tdt = dtype_code, torch_dtype
+        self.slots = 1 if slots else 0
+        self.pad = cfg['padding_idx']
+        dev = store.device
+        B, K, T, C, H, E, M = self.B, self.K, self.T, self.C, self.H, self.E, T * B
+        z = lambda shape, dt=None: torch.zeros(shape, dtype=dt or self.tdt, device=dev)
+        f32, i64 = torch.float32, torch.int64
+        self.ids = z((M,), i64)            # source words, time-major
+        self.tgt = z((M,), i64)
+        self.V0, self.Amean, self.g = z((B * K, H)), z((B, C)), z((B, H))
+        self.Vt = z((B * K, H))
+        self.Ve = z((B * K, H)) if slots else None
+        self.X = z((M, E + H))
+        self.G = z((M, 4 * H))
+        self.Hbuf, self.Cbuf = z(((T + 1) * B, H)), z(((T + 1) * B, H))
+        self.SGpre, self.S, self.P = z((M, H)), z((M, H)), z((M, H))
+        self.Q = z((M, H)) if slots else None
+        self.SE = z((M, H)) if slots else None
+        self.alpha = z((M, K + 1), f32)
+        self.CTXP, self.O, self.R = z((M, H)), z((M, H)), z((M, E))
+        self.logits = z((M, self.Vld), f32)
+        self.row_loss, self.row_lse = z((M,), f32), z((M,), f32)
+        self.loss, self.count = z((1,), f32), z((1,), f32)
+        if need_backward:
+            self.dlogits = z((M, self.Vld))
+            self.dR, self.dOpre, self.dCTXP = z((M, E)), z((M, H)), z((M, H))
+            self.dS, self.dPpre = z((M, H)), z((M, H))
+            self.dVt = z((B * K, H))
+            self.dVe = z((B * K, H)) if slots else None
+            self.dQ = z((M, H)) if slots else None
+            self.dSE = z((M, H)) if slots else None
+            self.de = z((M, K + 1), f32)
+            self.dHbuf, self.dCbuf = z(((T + 1) * B, H)), z(((T + 1) * B, H))
+            self.dSGpre, self.dX, self.dG = z((M, H)), z((M, E + H)), z((M, 4 * H))
+            self.dg, self.dV0, self.dAmean = z((B, H)), z((B * K, H)), z((B, C))
+
+    # ------------------------------------------------------------------ tiny helpers
+    def _gemm(self, plan, x, rows, K, w, N, y, ldw=None, ldx=None, ldy=None, bias=None, addend=None, ld_add=0,
+              act=ACT_NONE, dact=ACT_NONE, ysaved=None, ld_saved=0, out_f32=0):
+        """y[rows][N] = epilogue(x[rows][K] . w[N][K]^T); pointers may be ints (pre-offset)."""
+        g = gemm_geom(rows, K, ldx)
+        plan.add('capmi_igemm_nt', x, w, y, g, N, K if ldw is None else ldw, N if ldy is None else ldy, bias, addend,
+                 ld_add, ysaved, ld_saved, None, act, dact, out_f32, self.code)
+
+    def _wgrad(self, plan, x, rows, K, dy, N, dw, ldx=None, ldy=None, lddw=None):
+        """dw[N][K] += dy[rows][N]^T . x[rows][K]"""
+        g = gemm_geom(rows, K, ldx)
+        plan.add('capmi_igemm_tn_wgrad', x, dy, dw, g, N, N if ldy is None else ldy, K if lddw is None else lddw, self.code)
+
+    def _colsum(self, plan, a, rows, N, out, lda=None):
+        plan.add('capmi_colsum', a, rows, N, N if lda is None else lda, out, self.code)
+
+    def _fc(self, key):
+        return FC[key] + '.w_0', FC[key] + '.b_0'
+
+    # ------------------------------------------------------------------ shared forward pieces
+    def _plan_bridge(self, plan, A, W):
+        """`_img2feature` :191-199 and the pre-loop projections :52-53.  A = encoder output [B*K, C]."""
+        st, B, K, C, H = self.store, self.B, self.K, self.C, self.H
+        w0, b0 = self._fc('img_embed')
+        w1, b1 = self._fc('img_global')
+        w2, b2 = self._fc('img_feat')
+        w3, b3 = self._fc('img_feat_emb')
+        self._gemm(plan, _p(A), B * K, C, _p(W(w0)), H, _p(self.V0), bias=_p(st.view(b0)), act=ACT_RELU)          # :196
+        plan.add('capmi_mean_rows', _p(A), _p(self.Amean), B, K, C, self.code)                                    # :197
+        self._gemm(plan, _p(self.Amean), B, C, _p(W(w1)), H, _p(self.g), bias=_p(st.view(b1)), act=ACT_RELU)      # :198
+        self._gemm(plan, _p(self.V0), B * K, H, _p(W(w2)), H, _p(self.Vt), bias=_p(st.view(b2)), act=ACT_TANH)    # :52
+        if self.slots:
+            self._gemm(plan, _p(self.V0), B * K, H, _p(W(w3)), H, _p(self.Ve), bias=_p(st.view(b3)))              # :53
+
+    def _plan_post_lstm(self, plan, W, rows, X, Hprev, Hcur, Ccur, row0=0):
+        """Everything of one loop body after the lstm_unit (:89-117) for `rows` rows starting at
+        row `row0` of the time-major buffers; X/Hprev/Hcur/Ccur are pre-offset pointers."""
+        st, H, E, V = self.store, self.H, self.E, self.V
+        es = self.SGpre.element_size()
+        o = row0 * H * es
+        SG, S, P, CTXP, O = (_p(t) + o for t in (self.SGpre, self.S, self.P, self.CTXP, self.O))
+        R = _p(self.R) + row0 * E * es
+        w5, b5 = self._fc('p_word')
+        w6, b6 = self._fc('p_hidden')
+        w7, b7 = self._fc('p_hid')
+        w8, b8 = self._fc('hid_emb')
+        w9, b9 = self._fc('sent_emb')
+        w10, b10 = self._fc('alpha')
+        w11, b11 = self._fc('out')
+        w12, b12 = self._fc('proj')
+        self._gemm(plan, X, rows, E + H, _p(W(w5)), H, SG, bias=_p(st.view(b5)))                                  # :89
+        self._gemm(plan, Hprev, rows, H, _p(W(w6)), H, SG, bias=_p(st.view(b6)), addend=SG, ld_add=H)            # :90-91
+        plan.add('capmi_sentinel_fwd', SG, Ccur, S, rows * H, self.code)                                          # :91-92
+        self._gemm(plan, Hcur, rows, H, _p(W(w7)), H, P, bias=_p(st.view(b7)), act=ACT_TANH)                     # :99
+        Tn = rows // self.B
+        Q = SE = None
+        if self.slots:
+            Q, SE = _p(self.Q) + o, _p(self.SE) + o
+            self._gemm(plan, P, rows, H, _p(W(w8)), H, Q, bias=_p(st.view(b8)))                                   # :102
+            self._gemm(plan, S, rows, H, _p(W(w9)), H, SE, bias=_p(st.view(b9)))                                  # :104
+        alpha = _p(self.alpha) + row0 * (self.K + 1) * 4
+        plan.add('capmi_ada_attention_fwd', _p(self.Ve), _p(self.Vt), Q, SE, S, P, _p(W(w10)) if self.slots else None,
+                 _p(st.view(b10)), CTXP, alpha, Tn, self.B, self.K, H, self.slots, self.code)                     # :103-113
+        self._gemm(plan, CTXP, rows, H, _p(W(w11)), H, O, bias=_p(st.view(b11)), act=ACT_TANH)                   # :115
+        self._gemm(plan, O, rows, H, _p(W(w12)), E, R, bias=_p(st.view(b12)))                                    # :24
+        logits = _p(self.logits) + row0 * self.Vld * 4
+        self._gemm(plan, R, rows, E, _p(W('word_embedding')), V, logits, ldy=self.Vld,
+                   bias=_p(st.view('out_fc_bias')), out_f32=1)                                                    # :25
+
+    # ------------------------------------------------------------------ train forward
+    def plan_forward(self, plan, A, W):
+        st, B, K, T, H, E = self.store, self.B, self.K, self.T, self.H, self.E
+        M, code = T * B, self.code
+        es = self.X.element_size()
+        self._plan_bridge(plan, A, W)
+        # x_t = [embedding(w_t) ; g]  (:84-86), all steps at once
+        plan.add('capmi_embedding_fwd', _p(self.ids), _p(W('word_embedding')), _p(self.X), M, E, self.V, E + H, self.pad, code)
+        plan.add('capmi_bcast_rows', _p(self.g), _p(self.X), T, B, H, E + H, E, code)
+        # input part of the gates for every step: G = X . Wx^T + lstm_b   (lstm_w kernel layout [4H][E+H | H])
+        lw = W('lstm_w')
+        ldl = E + 2 * H
+        self._gemm(plan, _p(self.X), M, E + H, _p(lw), 4 * H, _p(self.G), ldw=ldl, bias=_p(st.view('lstm_b')))
+        wh = _p(lw) + (E + H) * es
+        for t in range(T):                                                                                        # :75-127
+            Gt = _p(self.G) + t * B * 4 * H * es
+            if t > 0:     # h_{-1} = 0 (:63): nothing to add at t = 0
+                self._gemm(plan, _p(self.Hbuf) + t * B * H * es, B, H, wh, 4 * H, Gt, ldw=ldl, addend=Gt, ld_add=4 * H)
+            plan.add('capmi_lstm_cell_fwd', Gt, _p(self.Cbuf) + t * B * H * es, _p(self.Hbuf) + (t + 1) * B * H * es,
+                     _p(self.Cbuf) + (t + 1) * B * H * es, B, H, code)                                            # :87-88
+        off1 = B * H * es
+        self._plan_post_lstm(plan, W, M, _p(self.X), _p(self.Hbuf), _p(self.Hbuf) + off1, _p(self.Cbuf) + off1)
+        plan.add('capmi_softmax_xent_fwd', _p(self.logits), _p(self.tgt), _p(self.row_loss), _p(self.row_lse), M, self.V,
+                 self.Vld, self.pad)                                                                              # :205-212
+        plan.add('capmi_xent_finalize', _p(self.row_loss), _p(self.tgt), _p(self.loss), _p(self.count), M, self.pad)  # :165-182
+
+    # ------------------------------------------------------------------ train backward
+    def plan_backward(self, plan, A, dA, W, WT):
+        """W(name): forward weights, WT(name): data-gradient forms.  Writes d(loss)/dA into dA and
+        accumulates every decoder parameter gradient into the store's flat gradient buffer."""
+        st, B, K, T, C, H, E, V, Vld = self.store, self.B, self.K, self.T, self.C, self.H, self.E, self.V, self.Vld
+        M, code = T * B, self.code
+        es = self.X.element_size()
+        g_ = lambda n: _p(st.gview(n))
+        w0, b0 = self._fc('img_embed')
+        w1, b1 = self._fc('img_global')
+        w2, b2 = self._fc('img_feat')
+        w3, b3 = self._fc('img_feat_emb')
+        w5, b5 = self._fc('p_word')
+        w6, b6 = self._fc('p_hidden')
+        w7, b7 = self._fc('p_hid')
+        w8, b8 = self._fc('hid_emb')
+        w9, b9 = self._fc('sent_emb')
+        w10, b10 = self._fc('alpha')
+        w11, b11 = self._fc('out')
+        w12, b12 = self._fc('proj')
+        # loss -> logits
+        plan.add('capmi_softmax_xent_bwd', _p(self.logits), _p(self.tgt), _p(self.row_lse), _p(self.count), _p(self.dlogits),
+                 M, V, Vld, Vld, self.pad, code)
+        # tied projection (:25): d bias, d Emb (dense part, quirk Q6), d proj
+        self._colsum(plan, _p(self.dlogits), M, V, g_('out_fc_bias'), lda=Vld)
+        self._wgrad(plan, _p(self.R), M, E, _p(self.dlogits), V, g_('word_embedding'), ldy=Vld)
+        self._gemm(plan, _p(self.dlogits), M, Vld, _p(WT('word_embedding')), E, _p(self.dR), ldw=Vld)
+        # fc_12 (:24) and fc_11 + tanh (:115)
+        self._wgrad(plan, _p(self.O), M, H, _p(self.dR), E, g_(w12))
+        self._colsum(plan, _p(self.dR), M, E, g_(b12))
+        self._gemm(plan, _p(self.dR), M, E, _p(WT(w12)), H, _p(self.dOpre), dact=ACT_TANH, ysaved=_p(self.O), ld_saved=H)
+        self._wgrad(plan, _p(self.CTXP), M, H, _p(self.dOpre), H, g_(w11))
+        self._colsum(plan, _p(self.dOpre), M, H, g_(b11))
+        self._gemm(plan, _p(self.dOpre), M, H, _p(WT(w11)), H, _p(self.dCTXP))
+        # attention (:97-113)
+        plan.add('capmi_ada_attention_bwd', _p(self.Ve), _p(self.Vt), _p(self.Q), _p(self.SE), _p(self.S),
+                 _p(W(w10)) if self.slots else None, _p(self.alpha), _p(self.dCTXP), _p(self.dS), _p(self.dVt), _p(self.dVe),
+                 _p(self.dQ), _p(self.dSE), g_(w10), g_(b10), _p(self.de), T, B, K, H, self.slots, code)
+        if self.slots:
+            self._wgrad(plan, _p(self.S), M, H, _p(self.dSE), H, g_(w9))
+            self._colsum(plan, _p(self.dSE), M, H, g_(b9))
+            self._gemm(plan, _p(self.dSE), M, H, _p(WT(w9)), H, _p(self.dS), addend=_p(self.dS), ld_add=H)
+            self._wgrad(plan, _p(self.P), M, H, _p(self.dQ), H, g_(w8))
+            self._colsum(plan, _p(self.dQ), M, H, g_(b8))
+            self._gemm(plan, _p(self.dQ), M, H, _p(WT(w8)), H, _p(self.dPpre), addend=_p(self.dCTXP), ld_add=H,
+                       dact=ACT_TANH, ysaved=_p(self.P), ld_saved=H)
+        else:
+            plan.add('capmi_act_bwd', _p(self.dCTXP), _p(self.P), _p(self.dPpre), 0, M * H, ACT_TANH, code)
+        # fc_7 (:99): p_hid = tanh(fc(h))
+        off1 = B * H * es
+        Hall, Hprev = _p(self.Hbuf) + off1, _p(self.Hbuf)
+        dHall, dCall = _p(self.dHbuf) + off1, _p(self.dCbuf) + off1
+        self._wgrad(plan, Hall, M, H, _p(self.dPpre), H, g_(w7))
+        self._colsum(plan, _p(self.dPpre), M, H, g_(b7))
+        self._gemm(plan, _p(self.dPpre), M, H, _p(WT(w7)), H, dHall)
+        # sentinel (:89-92)
+        plan.add('capmi_sentinel_bwd', _p(self.dS), _p(self.SGpre), _p(self.Cbuf) + off1, _p(self.dSGpre), dCall, M * H, code)
+        self._wgrad(plan, _p(self.X), M, E + H, _p(self.dSGpre), H, g_(w5))
+        self._wgrad(plan, Hprev, M, H, _p(self.dSGpre), H, g_(w6))
+        self._colsum(plan, _p(self.dSGpre), M, H, g_(b5))
+        self._colsum(plan, _p(self.dSGpre), M, H, g_(b6))
+        self._gemm(plan, _p(self.dSGpre), M, H, _p(WT(w5)), E + H, _p(self.dX))
+        # d h_{t-1} through fc_6 lands one row block earlier in dHbuf (block 0 = h_{-1}, unused)
+        self._gemm(plan, _p(self.dSGpre), M, H, _p(WT(w6)), H, _p(self.dHbuf), addend=_p(self.dHbuf), ld_add=H)
+        # BPTT through the lstm_unit (:87-88)
+        lwT = WT('lstm_w')                       # [E+2H][4H]
+        whT = _p(lwT) + (E + H) * 4 * H * es
+        for t in reversed(range(T)):
+            blk = lambda buf, i: _p(buf) + i * B * H * es
+            Gt = _p(self.G) + t * B * 4 * H * es
+            dGt = _p(self.dG) + t * B * 4 * H * es
+            plan.add('capmi_lstm_cell_bwd', Gt, blk(self.Cbuf, t), blk(self.Cbuf, t + 1), blk(self.dHbuf, t + 1),
+                     blk(self.dCbuf, t + 1), dGt, blk(self.dCbuf, t) if t > 0 else None, 1, B, H, code)
+            if t > 0:
+                self._gemm(plan, dGt, B, 4 * H, whT, H, blk(self.dHbuf, t), addend=blk(self.dHbuf, t), ld_add=H)
+        ldl = E + 2 * H
+        self._wgrad(plan, _p(self.X), M, E + H, _p(self.dG), 4 * H, g_('lstm_w'), lddw=ldl)
+        self._wgrad(plan, Hprev, M, H, _p(self.dG), 4 * H, g_('lstm_w') + (E + H) * 4, lddw=ldl)
+        self._colsum(plan, _p(self.dG), M, 4 * H, g_('lstm_b'))
+        self._gemm(plan, _p(self.dG), M, 4 * H, _p(lwT), E + H, _p(self.dX), addend=_p(self.dX), ld_add=E + H)
+        # x_t = [emb ; g] (:84-86)
+        plan.add('capmi_embedding_bwd', _p(self.ids), _p(self.dX), g_('word_embedding'), M, E, V, E + H, self.pad, code)
+        plan.add('capmi_bcast_rows_bwd', _p(self.dX), _p(self.dg), T, B, H, E + H, E, code)
+        # pre-loop projections (:52-53)
+        plan.add('capmi_act_bwd', _p(self.dVt), _p(self.Vt), _p(self.dVt), 0, B * K * H, ACT_TANH, code)
+        self._wgrad(plan, _p(self.V0), B * K, H, _p(self.dVt), H, g_(w2))
+        self._colsum(plan, _p(self.dVt), B * K, H, g_(b2))
+        if self.slots:
+            self._wgrad(plan, _p(self.V0), B * K, H, _p(self.dVe), H, g_(w3))
+            self._colsum(plan, _p(self.dVe), B * K, H, g_(b3))
+            self._gemm(plan, _p(self.dVe), B * K, H, _p(WT(w3)), H, _p(self.dV0))
+            self._gemm(plan, _p(self.dVt), B * K, H, _p(WT(w2)), H, _p(self.dV0), addend=_p(self.dV0), ld_add=H,
+                       dact=ACT_RELU, ysaved=_p(self.V0), ld_saved=H)
+        else:
+            self._gemm(plan, _p(self.dVt), B * K, H, _p(WT(w2)), H, _p(self.dV0), dact=ACT_RELU, ysaved=_p(self.V0), ld_saved=H)
+        # bridge (:191-199)
+        self._wgrad(plan, _p(A), B * K, C, _p(self.dV0), H, g_(w0))
+        self._colsum(plan, _p(self.dV0), B * K, H, g_(b0))
+        self._gemm(plan, _p(self.dV0), B * K, H, _p(WT(w0)), C, _p(dA))
+        plan.add('capmi_act_bwd', _p(self.dg), _p(self.g), _p(self.dg), 0, B * H, ACT_RELU, code)
+        self._wgrad(plan, _p(self.Amean), B, C, _p(self.dg), H, g_(w1))
+        self._colsum(plan, _p(self.dg), B, H, g_(b1))
+        self._gemm(plan, _p(self.dg), B, H, _p(WT(w1)), C, _p(self.dAmean))
+        plan.add('capmi_mean_rows_bwd', _p(self.dAmean), _p(dA), B, K, C, code)
+
+    # ------------------------------------------------------------------ greedy decode (eval graph)
+    def plan_greedy(self, plan, A, W, out_ids_f32, Ti):
+        """`eval_network` :185-189 + the eval branches of Decoder.call: first fed token start_idx
+        (:56-58, the caller fills self.ids[:B]), Ti = infer_max_length steps, no early stop (Q5),
+        argmax feedback (:119-121), ids written as float32 [B, Ti] (Q2)."""
+        st, B, H, E = self.store, self.B, self.H, self.E
+        assert self.T >= 1
+        code = self.code
+        es = self.X.element_size()
+        self._plan_bridge(plan, A, W)
+        plan.add('capmi_bcast_rows', _p(self.g), _p(self.X), 1, B, H, E + H, E, code)
+        lw = W('lstm_w')
+        ldl = E + 2 * H
+        wh = _p(lw) + (E + H) * es
+        # two (h, c) row blocks used alternately: block 0 starts as the zero state (:63)
+        for t in range(Ti):
+            cur, nxt = (t % 2), ((t + 1) % 2)
+            hp, cp = _p(self.Hbuf) + cur * B * H * es, _p(self.Cbuf) + cur * B * H * es
+            hn, cn = _p(self.Hbuf) + nxt * B * H * es, _p(self.Cbuf) + nxt * B * H * es
+            plan.add('capmi_embedding_fwd', _p(self.ids), _p(W('word_embedding')), _p(self.X), B, E, self.V, E + H, self.pad, code)
+            self._gemm(plan, _p(self.X), B, E + H, _p(lw), 4 * H, _p(self.G), ldw=ldl, bias=_p(st.view('lstm_b')))
+            self._gemm(plan, hp, B, H, wh, 4 * H, _p(self.G), ldw=ldl, addend=_p(self.G), ld_add=4 * H)
+            plan.add('capmi_lstm_cell_fwd', _p(self.G), cp, hn, cn, B, H, code)
+            self._plan_post_lstm(plan, W, B, _p(self.X), hp, hn, cn)
+            plan.add('capmi_argmax', _p(self.logits), _p(self.ids), _p(out_ids_f32) + t * 4, Ti, B, self.V, self.Vld)  # :120-123

@@ -1,0 +1,226 @@
+"""Encoder executor: turns an op list (arch.py) into launch plans of libcapmi kernels.
+
+Forward of one `conv -> batch_norm -> relu6` unit (the reference's `conv_bn_layer`,
+/root/reference/ImageCaptioning/model/MobileNetV2.py:88-121) is
+    implicit-GEMM conv (MFMA) with batch-norm statistics fused into its epilogue
+    -> bn_finalize (per-channel mean / invstd / affine coefficients, running-stat update)
+    -> bn_apply (normalise + activation, with the shortcut add of :123-124 folded in).
+Activations are NHWC in HBM, so the encoder output [B, S/32, S/32, C] already IS the
+[B, K, C] matrix `_img2feature` builds with reshape+transpose
+(model_adaAttention_aic.py:193-195).  Backward mirrors it: bn_bwd_reduce -> bn_bwd_apply ->
+weight-gradient GEMM (split over pixels, f32 atomics) -> data-gradient GEMM.
+"""
+import torch
+
+from . import arch
+from ._lib import ACT_CODES, ConvGeom, Plan, gemm_geom
+from .params import stem_kpad
+
+BN_MOMENTUM = 0.9      # fluid.layers.batch_norm defaults; MobileNetV2.py:112-117 overrides neither
+BN_EPS = 1e-5
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class EncoderRunner:
+    def __init__(self, store, B, S, dtype_code, torch_dtype, need_backward):
+        self.store, self.enc = store, store.enc
+        self.B, self.S = B, S
+        self.code, self.tdt = dtype_code, torch_dtype
+        self.dev = store.device
+        self.need_backward = need_backward
+        enc = self.enc
+        # ---- fold `add` ops into the bn_apply of the conv that produces their second operand
+        consumers = {}
+        for op in enc.ops:
+            srcs = (op.src,) if not isinstance(op, arch.Add) else (op.a, op.b)
+            for s in srcs:
+                consumers[s] = consumers.get(s, 0) + 1
+        producer = {op.dst: op for op in enc.ops}
+        self.fused_add = {}     # conv dst tensor id -> Add op folded into it
+        self.skipped = set()
+        for op in enc.ops:
+            if isinstance(op, arch.Add):
+                pb = producer.get(op.b)
+                if isinstance(pb, arch.ConvBN) and pb.act is None and consumers.get(op.b, 0) == 1:
+                    self.fused_add[pb.dst] = op
+                    self.skipped.add(id(op))
+        # ---- shapes and buffers
+        self.shape = {0: (S, S, 3)}
+        for op in enc.ops:
+            if isinstance(op, arch.ConvBN):
+                h, w, _ = self.shape[op.src]
+                ho = (h + 2 * op.pad - op.k) // op.stride + 1
+                wo = (w + 2 * op.pad - op.k) // op.stride + 1
+                self.shape[op.dst] = (ho, wo, op.cout)
+            elif isinstance(op, arch.Add):
+                self.shape[op.dst] = self.shape[op.a]
+            else:
+                h, w, c = self.shape[op.src]
+                self.shape[op.dst] = ((h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, c)
+        z = lambda shape, dt=None: torch.zeros(shape, dtype=dt or self.tdt, device=self.dev)
+        self.act, self.grad, self.raw, self.bn = {}, {}, {}, {}
+        self.pool_idx = {}
+        total_c = sum(op.cout for op in enc.ops if isinstance(op, arch.ConvBN))
+        self.stats = z((2 * total_c,), torch.float32)          # zeroed every step (fused BN statistics)
+        soff = 0
+        max_elems = 0
+        for op in enc.ops:
+            if id(op) in self.skipped:
+                continue
+            h, w, c = self.shape[op.dst]
+            out_id = self.fused_add[op.dst].dst if isinstance(op, arch.ConvBN) and op.dst in self.fused_add else op.dst
+            self.act[out_id] = z((B, h, w, c))
+            if need_backward:
+                self.grad[out_id] = z((B, h, w, c))
+            if isinstance(op, arch.ConvBN):
+                self.raw[op.dst] = z((B, h, w, c))
+                self.bn[op.dst] = dict(stats=self.stats[soff:soff + 2 * c], mean=z((c,), torch.float32),
+                                       invstd=z((c,), torch.float32), a=z((c,), torch.float32), b=z((c,), torch.float32))
+                soff += 2 * c
+                max_elems = max(max_elems, B * h * w * c)
+            elif isinstance(op, arch.MaxPool):
+                self.pool_idx[op.dst] = z((B, h, w, c), torch.uint8)
+        self.draw = z((max_elems,)) if need_backward else None          # grad w.r.t. a conv's raw output (scratch)
+        stem = enc.ops[0]
+        h, w, _ = self.shape[stem.dst]
+        self.kpad = stem_kpad(stem.k, stem.cin)
+        self.col = z((B * h * w, self.kpad))
+        self.out_id = enc.out
+
+    # ------------------------------------------------------------------ helpers
+    def _conv_geom(self, op):
+        hi, wi, _ = self.shape[op.src]
+        ho, wo, _ = self.shape[op.dst]
+        return ConvGeom(self.B, hi, wi, op.cin, ho, wo, op.k, op.k, op.stride, 1, op.pad, op.cin)
+
+    def _dgrad_geom(self, op):
+        hi, wi, _ = self.shape[op.src]
+        ho, wo, _ = self.shape[op.dst]
+        # "input" = dY [B,Ho,Wo,Cout]; output pixels = forward input pixels; flipped taps
+        return ConvGeom(self.B, ho, wo, op.cout, hi, wi, op.k, op.k, 1, op.stride, op.k - 1 - op.pad, op.cout)
+
+    def out_tensor(self):
+        return self.act[self.out_id]
+
+    def out_grad(self):
+        return self.grad[self.out_id]
+
+    # ------------------------------------------------------------------ forward plan
+    def plan_forward(self, plan, image, weights, update_running=True):
+        """image: f32 NCHW [B,3,S,S] device tensor (the reference feed).  weights(name) -> tensor
+        the kernels read (f32 master or bf16 shadow)."""
+        st, B, code = self.store, self.B, self.code
+        plan.add('capmi_fill_f32', _p(self.stats), 0.0, self.stats.numel())
+        for op in self.enc.ops:
+            if id(op) in self.skipped:
+                continue
+            if isinstance(op, arch.ConvBN):
+                ho, wo, c = self.shape[op.dst]
+                M = B * ho * wo
+                bn = self.bn[op.dst]
+                raw = self.raw[op.dst]
+                w = weights(op.name + '_weights')
+                if op.src == 0:        # stem: explicit im2col of the NCHW feed, then a plain GEMM
+                    plan.add('capmi_im2col_stem', _p(image), _p(self.col), B, op.cin, self.S, self.S, op.k, op.stride,
+                             op.pad, ho, wo, self.kpad, code)
+                    g = gemm_geom(M, self.kpad)
+                    plan.add('capmi_igemm_nt', _p(self.col), _p(w), _p(raw), g, c, self.kpad, c, None, None, 0, None, 0,
+                             _p(bn['stats']), 0, 0, 0, code)
+                elif op.groups > 1:
+                    hi, wi, _ = self.shape[op.src]
+                    plan.add('capmi_dwconv3x3_fwd', _p(self.act[op.src]), _p(w), _p(raw), B, hi, wi, c, op.stride, ho, wo, code)
+                    plan.add('capmi_bn_stats', _p(raw), M, c, _p(bn['stats']), code)
+                else:
+                    g = self._conv_geom(op)
+                    K = op.k * op.k * op.cin
+                    plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
+                             _p(bn['stats']), 0, 0, 0, code)
+                plan.add('capmi_bn_finalize', _p(bn['stats']), M, c, _p(st.view(op.name + '_bn_scale')),
+                         _p(st.view(op.name + '_bn_offset')), _p(st.state[op.name + '_bn_mean']),
+                         _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS, _p(bn['mean']), _p(bn['invstd']),
+                         _p(bn['a']), _p(bn['b']), 1 if update_running else 0)
+                fa = self.fused_add.get(op.dst)
+                if fa is None:
+                    plan.add('capmi_bn_apply', _p(raw), _p(bn['a']), _p(bn['b']), None, _p(self.act[op.dst]), M, c,
+                             ACT_CODES[op.act], code)
+                else:
+                    plan.add('capmi_bn_apply', _p(raw), _p(bn['a']), _p(bn['b']), _p(self.act[fa.a]), _p(self.act[fa.dst]),
+                             M, c, ACT_CODES[fa.act], code)
+            elif isinstance(op, arch.Add):
+                n = self.act[op.dst].numel()
+                plan.add('capmi_add_act', _p(self.act[op.a]), _p(self.act[op.b]), _p(self.act[op.dst]), n, ACT_CODES[op.act], code)
+            else:
+                hi, wi, c = self.shape[op.src]
+                ho, wo, _ = self.shape[op.dst]
+                plan.add('capmi_maxpool3x3s2_fwd', _p(self.act[op.src]), _p(self.act[op.dst]), _p(self.pool_idx[op.dst]),
+                         B, hi, wi, c, ho, wo, code)
+
+    # ------------------------------------------------------------------ backward plan
+    def plan_backward(self, plan, weights, weights_bwd, segments=None):
+        """Expects d(loss)/d(encoder output) in self.out_grad().  weights(name) -> forward filter,
+        weights_bwd(name) -> its data-gradient form.  `segments`, if given, is a list that receives (plan_index, param_name)
+        marks after each op's parameter gradients are final (used to place all-reduce buckets)."""
+        assert self.need_backward
+        st, B, code = self.store, self.B, self.code
+        written = {self.out_id}
+        for op in reversed(self.enc.ops):
+            if id(op) in self.skipped:
+                continue
+            if isinstance(op, arch.ConvBN):
+                ho, wo, c = self.shape[op.dst]
+                M = B * ho * wo
+                bn = self.bn[op.dst]
+                raw = self.raw[op.dst]
+                fa = self.fused_add.get(op.dst)
+                out_id = fa.dst if fa else op.dst
+                act = ACT_CODES[fa.act if fa else op.act]
+                dy, y = self.grad[out_id], self.act[out_id]
+                red = st.gview(op.name + '_bn_offset')        # [d offset | d scale] adjacent in the flat buffer
+                assert c % 8 == 0 and st.entries[op.name + '_bn_scale'].offset == st.entries[op.name + '_bn_offset'].offset + c
+                plan.add('capmi_bn_bwd_reduce', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']), _p(red), M, c, act, code)
+                dres, dres_acc = None, 0
+                if fa is not None and fa.a != 0:
+                    dres = self.grad[fa.a]
+                    dres_acc = 1 if fa.a in written else 0
+                    written.add(fa.a)
+                plan.add('capmi_bn_bwd_apply', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
+                         _p(st.view(op.name + '_bn_scale')), _p(red), _p(self.draw), 0, _p(dres), dres_acc, M, c, act, code)
+                dwt = st.gview(op.name + '_weights')
+                if op.src == 0:
+                    g = gemm_geom(M, self.kpad)
+                    plan.add('capmi_igemm_tn_wgrad', _p(self.col), _p(self.draw), _p(dwt), g, c, c, self.kpad, code)
+                elif op.groups > 1:
+                    hi, wi, _ = self.shape[op.src]
+                    plan.add('capmi_dwconv3x3_bwd_weight', _p(self.act[op.src]), _p(self.draw), _p(dwt), B, hi, wi, c, op.stride, ho, wo, code)
+                    acc = 1 if op.src in written else 0
+                    plan.add('capmi_dwconv3x3_bwd_data', _p(self.draw), _p(weights(op.name + '_weights')), _p(self.grad[op.src]),
+                             B, hi, wi, c, op.stride, ho, wo, acc, code)
+                    written.add(op.src)
+                else:
+                    g = self._conv_geom(op)
+                    K = op.k * op.k * op.cin
+                    plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(self.draw), _p(dwt), g, c, c, K, code)
+                    dx = self.grad[op.src]
+                    acc = op.src in written
+                    gd = self._dgrad_geom(op)
+                    Kd = op.k * op.k * op.cout
+                    plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd(op.name + '_weights')), _p(dx), gd, op.cin, Kd, op.cin,
+                             None, _p(dx) if acc else None, op.cin, None, 0, None, 0, 0, 0, code)
+                    written.add(op.src)
+                if segments is not None:
+                    segments.append((len(plan), op.name))
+            elif isinstance(op, arch.Add):
+                n = self.act[op.dst].numel()
+                for t in (op.a, op.b):
+                    plan.add('capmi_act_bwd', _p(self.grad[op.dst]), _p(self.act[op.dst]), _p(self.grad[t]), 1 if t in written else 0,
+                             n, ACT_CODES[op.act], code)
+                    written.add(t)
+            else:
+                hi, wi, c = self.shape[op.src]
+                ho, wo, _ = self.shape[op.dst]
+                assert op.src not in written
+                plan.add('capmi_maxpool3x3s2_bwd', _p(self.grad[op.dst]), _p(self.pool_idx[op.dst]), _p(self.grad[op.src]), B, hi, wi, c, ho, wo, code)
+                written.add(op.src)

@@ -1,0 +1,330 @@
+"""`ImageCaptionModel` facade + execution engine: the drop-in for the reference's model/ package
+and the `train_exe.run(...)` step of train.py.
+
+Reference protocol being mirrored (/root/reference/ImageCaptioning/):
+  model/model_adaAttention_aic.py:138-212  ImageCaptionModel.build_input / build_network
+  train.py:34-58                           training_net() / eval_net()
+  train.py:121-127,139,163                 ParallelExecutor(...).run(feed=..., fetch_list=[...])
+Feeds: `image` float32 [B,3,S,S] (NCHW), `caption` int64 [B,L].  Fetches: loss float32 [1],
+lr float32 [1]; eval `caption` ids float32 [B,Ti] (quirk Q2).  Errors: ValueError on a bad
+mode, AssertionError on NaN loss (train.py:140-141) are raised by the callers in train_loop.py.
+
+All arithmetic runs in libcapmi.so (hand-written gfx950 kernels) through static launch plans;
+torch only owns device memory, streams, hipGraph capture and torch.distributed.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, Plan
+from .decoder import DecoderRunner, vocab_ld
+from .encoder import EncoderRunner
+from .optim import ADAM_BETA1, ADAM_BETA2, ADAM_EPS, LRSchedule, adam_lr_t
+from .params import ParamStore
+
+_DTYPES = {'f32': (F32, torch.float32), 'bf16': (BF16, torch.bfloat16)}
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+class Var:
+    """Stand-in for a fluid Variable handle: only its name matters (fetch/feed lookup)."""
+
+    def __init__(self, name, shape, dtype):
+        self.name, self.shape, self.dtype = name, shape, dtype
+
+    def __repr__(self):
+        return 'Var(%s, %s, %s)' % (self.name, self.shape, self.dtype)
+
+
+class CaptionEngine:
+    """Owns parameters, weight shadows, static buffers and launch plans for one device."""
+
+    def __init__(self, cfg, device='cuda:0', use_graph=True, process_group=None):
+        self.cfg = dict(cfg)
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.CapmiError('CaptionEngine needs a HIP device (got %s); there is no CPU path' % device)
+        _lib.lib()                                   # fail loudly if the extension is missing
+        self.code, self.tdt = _DTYPES[cfg.get('dtype', 'f32')]
+        self.slots = cfg.get('attention', 'singleton') == 'slots'
+        if cfg.get('attention', 'singleton') not in ('singleton', 'slots'):
+            raise ValueError('不支持{}'.format(cfg['attention']))
+        self.store = ParamStore(self.cfg, self.device)
+        self.store.init_reference(seed=cfg.get('seed') or 0)
+        self.use_graph = use_graph
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        self.lr_schedule = LRSchedule(cfg.get('lr_decay_strategy'), cfg.get('learning_rate', 5e-5),
+                                      cfg.get('sample_count', 0), cfg.get('batch_size', 1), cfg.get('decay_epoch', 0),
+                                      cfg.get('warmup_epoch', 3), cfg.get('max_epoch', 10))
+        self.step_count = 0
+        self._build_shadows()
+        self._train = {}      # batch size -> compiled train program
+        self._eval = {}
+        self.shadows_dirty = True
+
+    # ------------------------------------------------------------------ weight shadows
+    def _build_shadows(self):
+        """bf16 mode: `low` = bf16 copy of the flat parameter buffer (same offsets).  Both modes:
+        `wT` = data-gradient forms ([C][kh][kw][N], taps flipped) of every GEMM weight."""
+        st = self.store
+        self.low = torch.zeros(st.size, dtype=self.tdt, device=self.device) if self.code == BF16 else None
+        self.wT_entries = {}
+        off = 0
+        V, E = self.cfg['vocab'], self.cfg['embed']
+        for name, e in st.entries.items():
+            if e.kind == 'conv':
+                n, kh, kw, c = e.kshape
+                spec = (n, kh, kw, c, n)
+            elif e.kind == 'fc_w':
+                n, k = e.kshape
+                spec = (n, 1, 1, k, n)
+            elif name == 'word_embedding':
+                spec = (V, 1, 1, E, vocab_ld(V))
+            else:
+                continue
+            size = spec[3] * spec[1] * spec[2] * spec[4]
+            self.wT_entries[name] = (off, spec)
+            off += (size + 7) // 8 * 8
+        self.wT = torch.zeros(off, dtype=self.tdt, device=self.device)
+        self.shadow_plan = Plan()
+        if self.code == BF16:
+            self.shadow_plan.add('capmi_cast', _p(st.flat), _p(self.low), st.size, self.code)
+        for name, (o, (n, kh, kw, c, ldt)) in self.wT_entries.items():
+            self.shadow_plan.add('capmi_weight_dgrad_form', _p(st.view(name)), _p(self.wT) + o * self.wT.element_size(),
+                                 n, kh, kw, c, ldt, self.code)
+
+    def W(self, name):
+        return self.store.view(name) if self.low is None else self.store.view(name, self.low)
+
+    def WT(self, name):
+        o, (n, kh, kw, c, ldt) = self.wT_entries[name]
+        return self.wT[o:o + c * kh * kw * ldt]
+
+    def refresh_shadows(self):
+        self.shadow_plan.run(self._stream())
+        self.shadows_dirty = False
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    # ------------------------------------------------------------------ parameters in / out
+    def load_reference_params(self, params):
+        self.store.load_reference(params)
+        self.shadows_dirty = True
+
+    def export_reference_params(self):
+        torch.cuda.synchronize(self.device)
+        return self.store.export_reference()
+
+    def export_reference_grads(self):
+        torch.cuda.synchronize(self.device)
+        return self.store.export_reference_grads()
+
+    # ------------------------------------------------------------------ program construction
+    def _compile_train(self, B):
+        cfg, S = self.cfg, self.cfg['image_size']
+        need_enc_bwd = bool(cfg['encoder_trainable'])
+        enc = EncoderRunner(self.store, B, S, self.code, self.tdt, True)
+        K = enc.shape[enc.out_id][0] * enc.shape[enc.out_id][1]
+        T = cfg['sentence_length'] - 1                                         # model_adaAttention_aic.py:66
+        dec = DecoderRunner(self.store, B, K, T, self.code, self.tdt, self.slots, True)
+        image = torch.zeros((B, 3, S, S), dtype=torch.float32, device=self.device)
+        fwd, bwd = Plan(), Plan()
+        enc.plan_forward(fwd, image, self.W)
+        dec.plan_forward(fwd, enc.out_tensor(), self.W)
+        bwd.add('capmi_fill_f32', _p(self.store.grad), 0.0, self.store.size)
+        dec.plan_backward(bwd, enc.out_tensor(), enc.out_grad(), self.W, self.WT)
+        marks = []
+        n_dec = len(bwd)
+        if need_enc_bwd:
+            enc.plan_backward(bwd, self.W, self.WT, marks)
+        prog = dict(B=B, enc=enc, dec=dec, image=image, fwd=fwd, bwd=bwd, graph=None, marks=marks, n_dec=n_dec)
+        return prog
+
+    def _compile_eval(self, B):
+        cfg, S = self.cfg, self.cfg['image_size']
+        enc = EncoderRunner(self.store, B, S, self.code, self.tdt, False)
+        K = enc.shape[enc.out_id][0] * enc.shape[enc.out_id][1]
+        Ti = cfg['infer_max_length']
+        dec = DecoderRunner(self.store, B, K, 1, self.code, self.tdt, self.slots, False)
+        image = torch.zeros((B, 3, S, S), dtype=torch.float32, device=self.device)
+        out = torch.zeros((B, Ti), dtype=torch.float32, device=self.device)
+        plan = Plan()
+        # in-training eval graph: batch statistics AND running-stat update (quirk Q3)
+        enc.plan_forward(plan, image, self.W, update_running=True)
+        es = dec.Hbuf.element_size()
+        plan.add('capmi_fill_f32', _p(dec.Hbuf), 0.0, B * dec.H * es // 4)
+        plan.add('capmi_fill_f32', _p(dec.Cbuf), 0.0, B * dec.H * es // 4)
+        dec.plan_greedy(plan, enc.out_tensor(), self.W, out, Ti)
+        return dict(B=B, enc=enc, dec=dec, image=image, out=out, plan=plan, graph=None)
+
+    def _run_captured(self, prog, key, plans):
+        """Replays `plans` from a hipGraph captured on first use (static shapes and pointers)."""
+        if not self.use_graph:
+            for p in plans:
+                p.run(self._stream())
+            return
+        if prog.get(key) is None:
+            # warm-up outside capture so lazy module loading does not happen inside it
+            for p in plans:
+                p.run(self._stream())
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for p in plans:
+                    p.run(self._stream())
+            prog[key] = g
+            return            # the warm-up run already produced this call's results
+        prog[key].replay()
+
+    # ------------------------------------------------------------------ feeds
+    @staticmethod
+    def _as_tensor(x, dtype, device):
+        t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+        return t.to(device=device, dtype=dtype, non_blocking=True)
+
+    def _feed_train(self, prog, image, caption):
+        cfg = self.cfg
+        B, dec = prog['B'], prog['dec']
+        img = self._as_tensor(image, torch.float32, self.device)
+        cap = self._as_tensor(caption, torch.int64, self.device)
+        if tuple(img.shape) != tuple(prog['image'].shape):
+            raise ValueError('image feed must be %s, got %s' % (tuple(prog['image'].shape), tuple(img.shape)))
+        if tuple(cap.shape) != (B, cfg['sentence_length']):
+            raise ValueError('caption feed must be %s, got %s' % ((B, cfg['sentence_length']), tuple(cap.shape)))
+        prog['image'].copy_(img)
+        dec.ids.copy_(cap[:, :-1].t().reshape(-1))          # source = caption[:, :-1] (:164), time-major (:60)
+        dec.tgt.copy_(cap[:, 1:].t().reshape(-1))           # target = caption[:, 1:]  (:163)
+
+    # ------------------------------------------------------------------ public steps
+    def forward_backward(self, image, caption):
+        """One forward + backward on this rank's batch; gradients land in store.grad.  Returns the
+        device loss tensor (float32 [1], named 'loss' in the reference, :182)."""
+        B = int(image.shape[0])
+        prog = self._train.get(B)
+        if prog is None:
+            prog = self._train[B] = self._compile_train(B)
+        if self.shadows_dirty:
+            self.refresh_shadows()
+        self._feed_train(prog, image, caption)
+        self._run_captured(prog, 'graph', [prog['fwd'], prog['bwd']])
+        return prog['dec'].loss
+
+    def forward_loss(self, image, caption):
+        """Forward only (no gradient, running statistics still updated as in the train graph)."""
+        B = int(image.shape[0])
+        prog = self._train.get(B)
+        if prog is None:
+            prog = self._train[B] = self._compile_train(B)
+        if self.shadows_dirty:
+            self.refresh_shadows()
+        self._feed_train(prog, image, caption)
+        prog['fwd'].run(self._stream())
+        return prog['dec'].loss
+
+    def optimizer_step(self):
+        """Paddle-form Adam over the trainable slice of the flat buffers (IC/train.py:26-31,45)."""
+        cfg = self.cfg
+        lr = self.lr_schedule.value(self.step_count)
+        self.step_count += 1
+        clip = float(cfg['gradient_clip']) if cfg.get('gradient_clip') else 0.0
+        st = self.store
+        _lib.call('capmi_adam', _p(st.flat), _p(st.grad), _p(st.adam_m), _p(st.adam_v), st.trainable_size,
+                  adam_lr_t(lr, self.step_count), ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, 1.0 / self.world, self._stream())
+        self.shadows_dirty = True
+        return lr
+
+    def allreduce_grads(self):
+        """Sum of the per-rank gradients (ParallelExecutor's AllReduce strategy, IC/train.py:121-124);
+        the 1/N CoeffNumDevice scale is applied inside the Adam kernel."""
+        if self.world > 1:
+            torch.distributed.all_reduce(self.store.grad[:self.store.trainable_size], group=self.pg)
+
+    def train_step(self, image, caption):
+        """feed -> fwd -> bwd -> (all-reduce) -> Adam; returns (loss tensor [1], lr float)."""
+        loss = self.forward_backward(image, caption)
+        self.allreduce_grads()
+        lr = self.optimizer_step()
+        self.refresh_shadows()
+        return loss, lr
+
+    def decode(self, image):
+        """Greedy decode of the in-training eval graph: float32 ids [B, infer_max_length]."""
+        B = int(image.shape[0])
+        prog = self._eval.get(B)
+        if prog is None:
+            prog = self._eval[B] = self._compile_eval(B)
+        if self.shadows_dirty:
+            self.refresh_shadows()
+        img = self._as_tensor(image, torch.float32, self.device)
+        if tuple(img.shape) != tuple(prog['image'].shape):
+            raise ValueError('image feed must be %s, got %s' % (tuple(prog['image'].shape), tuple(img.shape)))
+        prog['image'].copy_(img)
+        prog['dec'].ids[:B].fill_(self.cfg['start_idx'])                   # :56-58
+        self._run_captured(prog, 'graph', [prog['plan']])
+        return prog['out']
+
+
+class ImageCaptionModel:
+    """Same construction protocol as the reference class (model_adaAttention_aic.py:138-203)."""
+
+    def __init__(self, cfg=None, engine=None, **engine_kw):
+        from .config_compat import default_cfg
+        self.cfg = default_cfg() if cfg is None else cfg
+        self._engine = engine
+        self._engine_kw = engine_kw
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = CaptionEngine(self.cfg, **self._engine_kw)
+        return self._engine
+
+    def build_input(self, mode='train'):
+        if mode not in ['train', 'eval']:
+            raise ValueError('不支持{}'.format(mode))                         # :144-145
+        S = self.cfg['image_size']
+        img = Var('image', [-1, 3, S, S], 'float32')                          # :146
+        if mode == 'train':
+            caption = Var('caption', [-1, self.cfg['sentence_length']], 'int64')   # :149
+            return {'img': img, 'caption': caption}, [img, caption]
+        return {'img': img}, [img]
+
+    def build_network(self, mode='train', **kwargs):
+        if mode not in ['train', 'eval']:
+            raise ValueError('不支持{}'.format(mode))                         # :154-155
+        if mode == 'train':
+            return Var('loss', [1], 'float32')                                # :182
+        return Var('caption', [-1, self.cfg['infer_max_length']], 'float32')  # :185-189 (float ids, Q2)
+
+    @staticmethod
+    def first_init(places):
+        pass                                                                  # :201-203
+
+
+class Executor:
+    """`fluid.ParallelExecutor`-shaped driver: run(feed=..., fetch_list=[...]) (train.py:139,163)."""
+
+    def __init__(self, model, lr_var=None):
+        self.model = model
+        self.lr_var = lr_var or Var('learning_rate', [1], 'float32')
+
+    def run(self, feed, fetch_list):
+        names = [f.name if isinstance(f, Var) else f for f in fetch_list]
+        eng = self.model.engine
+        out = []
+        if 'loss' in names:
+            loss, lr = eng.train_step(feed['image'], feed['caption'])
+            res = {'loss': loss.detach().cpu().numpy().astype(np.float32),
+                   self.lr_var.name: np.array([lr], dtype=np.float32)}
+        elif 'caption' in names:
+            res = {'caption': eng.decode(feed['image']).detach().cpu().numpy()}
+        else:
+            raise ValueError('unknown fetch %r' % (names,))
+        for n in names:
+            out.append(res[n])
+        return out

@@ -1,0 +1,422 @@
+"""Kernel-level parity (MI355X only): every libcapmi.so kernel family, called through the C ABI,
+against the NumPy oracle ops on the same seeded inputs.  f32 runs at reference precision
+(tight tolerance); bf16 compares against the oracle evaluated on bf16-rounded inputs with a
+tolerance set by bf16's 8-bit mantissa."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+TOL = {'f32': dict(rtol=2e-4, atol=2e-4), 'bf16': dict(rtol=3e-2, atol=3e-2)}
+
+
+def _env():
+    from myimagecaptioningmodel_amd import _lib
+    tdt = {'f32': torch.float32, 'bf16': torch.bfloat16}
+    code = {'f32': _lib.F32, 'bf16': _lib.BF16}
+    return _lib, tdt, code
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dev(a, dt):
+    return torch.as_tensor(np.ascontiguousarray(a)).to(device=DEV, dtype=dt)
+
+
+def rnd(a, dtype):
+    """Round a float64 array through the storage dtype (what the kernel actually reads)."""
+    if dtype == 'bf16':
+        return torch.as_tensor(a, dtype=torch.float32).to(torch.bfloat16).to(torch.float64).numpy()
+    return a.astype(np.float32).astype(np.float64)
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().to(torch.float64).cpu().numpy()
+
+
+def p(t):
+    return None if t is None else t.data_ptr()
+
+
+def check(got, want, dtype, scale=None, name=''):
+    tol = TOL[dtype]
+    s = np.abs(want).max() if scale is None else scale
+    err = np.abs(got - want).max()
+    assert err <= tol['atol'] * max(1.0, s) , '%s: max err %g (scale %g)' % (name, err, s)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 32), (200, 72, 40), (130, 136, 104), (1216, 1000, 64), (37, 8, 16), (300, 260, 512)])
+def test_gemm_nt_epilogues(dtype, M, N, K):
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(M + N + K)
+    a = rnd(rng.standard_normal((M, K)), dtype)
+    w = rnd(rng.standard_normal((N, K)) / np.sqrt(K), dtype)
+    bias = rng.standard_normal(N).astype(np.float32)
+    add = rnd(rng.standard_normal((M, N)), dtype)
+    ysaved = rnd(np.tanh(rng.standard_normal((M, N))), dtype)
+    A, W = dev(a, tdt[dtype]), dev(w, tdt[dtype])
+    # plain + bias + tanh
+    Y = torch.zeros((M, N), dtype=tdt[dtype], device=DEV)
+    g = _lib.gemm_geom(M, K)
+    _lib.call('capmi_igemm_nt', p(A), p(W), p(Y), g, N, K, N, p(dev(bias, torch.float32)), None, 0, None, 0, None,
+              _lib.ACT_TANH, 0, 0, code[dtype], stream())
+    check(host(Y), np.tanh(a @ w.T + bias), dtype, name='bias+tanh')
+    # addend + dact + f32 output + stats
+    Y32 = torch.zeros((M, N), dtype=torch.float32, device=DEV)
+    stats = torch.zeros(2 * N, dtype=torch.float32, device=DEV)
+    _lib.call('capmi_igemm_nt', p(A), p(W), p(Y32), g, N, K, N, None, p(dev(add, tdt[dtype])), N, p(dev(ysaved, tdt[dtype])), N,
+              p(stats), 0, _lib.ACT_TANH, 1, code[dtype], stream())
+    pre = a @ w.T + add
+    check(host(Y32), pre * (1 - ysaved ** 2), dtype, name='addend+dact')
+    st = host(stats)
+    check(st[:N], pre.sum(0), dtype, scale=np.abs(pre).sum(0).max(), name='stats sum')
+    check(st[N:], (pre ** 2).sum(0), dtype, scale=(pre ** 2).sum(0).max(), name='stats sumsq')
+
+
+def _nhwc(x):
+    return np.ascontiguousarray(x.transpose(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('B,C,H,W,Co,k,s,pad', [(2, 16, 9, 9, 24, 3, 1, 1), (3, 8, 12, 10, 40, 3, 2, 1), (2, 32, 8, 8, 16, 1, 1, 0),
+                                                (2, 16, 8, 8, 32, 1, 2, 0), (1, 64, 14, 14, 64, 3, 1, 1)])
+def test_conv_fwd_dgrad_wgrad(dtype, B, C, H, W, Co, k, s, pad):
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(B * C + Co + k + s)
+    x = rnd(rng.standard_normal((B, C, H, W)), dtype)
+    w = rnd(rng.standard_normal((Co, C, k, k)) / np.sqrt(C * k * k), dtype)
+    y = O.conv2d_fwd(x, w, s, pad)
+    Ho, Wo = y.shape[2], y.shape[3]
+    dy = rnd(rng.standard_normal(y.shape), dtype)
+    dx, dw = O.conv2d_bwd(dy, x, w, s, pad)
+    X = dev(_nhwc(x), tdt[dtype])
+    Wk = dev(w.transpose(0, 2, 3, 1), tdt[dtype])                    # [Co][kh][kw][C]
+    Y = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+    g = _lib.ConvGeom(B, H, W, C, Ho, Wo, k, k, s, 1, pad, C)
+    _lib.call('capmi_igemm_nt', p(X), p(Wk), p(Y), g, Co, k * k * C, Co, None, None, 0, None, 0, None, 0, 0, 0, code[dtype], stream())
+    check(host(Y), _nhwc(y), dtype, name='conv fwd')
+    # weight gradient
+    DY = dev(_nhwc(dy), tdt[dtype])
+    DW = torch.zeros((Co, k, k, C), dtype=torch.float32, device=DEV)
+    _lib.call('capmi_igemm_tn_wgrad', p(X), p(DY), p(DW), g, Co, Co, k * k * C, code[dtype], stream())
+    check(host(DW), dw.transpose(0, 2, 3, 1), dtype, name='conv wgrad')
+    # data gradient through the flipped/transposed weight form
+    WT = torch.zeros((C, k, k, Co), dtype=tdt[dtype], device=DEV)
+    _lib.call('capmi_weight_dgrad_form', p(dev(w.transpose(0, 2, 3, 1), torch.float32)), p(WT), Co, k, k, C, Co, code[dtype], stream())
+    DX = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+    gd = _lib.ConvGeom(B, Ho, Wo, Co, H, W, k, k, 1, s, k - 1 - pad, Co)
+    _lib.call('capmi_igemm_nt', p(DY), p(WT), p(DX), gd, C, k * k * Co, C, None, None, 0, None, 0, None, 0, 0, 0, code[dtype], stream())
+    check(host(DX), _nhwc(dx), dtype, name='conv dgrad')
+    # accumulate form: dX += ...
+    _lib.call('capmi_igemm_nt', p(DY), p(WT), p(DX), gd, C, k * k * Co, C, None, p(DX), C, None, 0, None, 0, 0, 0, code[dtype], stream())
+    check(host(DX), 2 * _nhwc(dx), dtype, name='conv dgrad accumulate')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('M,N,K', [(1216, 40, 48), (64, 264, 136), (5000, 16, 24), (333, 1000, 32)])
+def test_fc_wgrad_and_colsum(dtype, M, N, K):
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(M + N)
+    x = rnd(rng.standard_normal((M, K)), dtype)
+    ldy = (N + 7) // 8 * 8
+    dy = np.zeros((M, ldy))
+    dy[:, :N] = rnd(rng.standard_normal((M, N)), dtype)
+    X, DY = dev(x, tdt[dtype]), dev(dy, tdt[dtype])
+    DW = torch.zeros((N, K), dtype=torch.float32, device=DEV)
+    _lib.call('capmi_igemm_tn_wgrad', p(X), p(DY), p(DW), _lib.gemm_geom(M, K), N, ldy, K, code[dtype], stream())
+    want = dy[:, :N].T @ x
+    check(host(DW), want, dtype, name='fc wgrad')
+    DB = torch.zeros(N, dtype=torch.float32, device=DEV)
+    _lib.call('capmi_colsum', p(DY), M, N, ldy, p(DB), code[dtype], stream())
+    check(host(DB), dy[:, :N].sum(0), dtype, scale=np.abs(dy).sum(0).max(), name='colsum')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('stride', [1, 2])
+def test_depthwise(dtype, stride):
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(stride)
+    B, C, H, W = 2, 24, 9, 11
+    x = rnd(rng.standard_normal((B, C, H, W)), dtype)
+    w = rnd(rng.standard_normal((C, 1, 3, 3)), dtype)
+    y = O.conv2d_fwd(x, w, stride, 1, groups=C)
+    Ho, Wo = y.shape[2:]
+    dy = rnd(rng.standard_normal(y.shape), dtype)
+    dx, dw = O.conv2d_bwd(dy, x, w, stride, 1, groups=C)
+    X, Wk, DY = dev(_nhwc(x), tdt[dtype]), dev(w[:, 0].transpose(1, 2, 0), tdt[dtype]), dev(_nhwc(dy), tdt[dtype])
+    Y = torch.zeros((B, Ho, Wo, C), dtype=tdt[dtype], device=DEV)
+    _lib.call('capmi_dwconv3x3_fwd', p(X), p(Wk), p(Y), B, H, W, C, stride, Ho, Wo, code[dtype], stream())
+    check(host(Y), _nhwc(y), dtype, name='dw fwd')
+    DX = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+    _lib.call('capmi_dwconv3x3_bwd_data', p(DY), p(Wk), p(DX), B, H, W, C, stride, Ho, Wo, 0, code[dtype], stream())
+    check(host(DX), _nhwc(dx), dtype, name='dw dgrad')
+    DW = torch.zeros((3, 3, C), dtype=torch.float32, device=DEV)
+    _lib.call('capmi_dwconv3x3_bwd_weight', p(X), p(DY), p(DW), B, H, W, C, stride, Ho, Wo, code[dtype], stream())
+    check(host(DW), dw[:, 0].transpose(1, 2, 0), dtype, name='dw wgrad')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_maxpool_and_stem_im2col(dtype):
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(3)
+    B, C, H, W = 2, 16, 9, 12
+    x = rnd(rng.standard_normal((B, C, H, W)), dtype)
+    y, idx = O.maxpool3x3s2_fwd(x)
+    Ho, Wo = y.shape[2:]
+    dy = rnd(rng.standard_normal(y.shape), dtype)
+    dx = O.maxpool3x3s2_bwd(dy, idx, x.shape)
+    X, DY = dev(_nhwc(x), tdt[dtype]), dev(_nhwc(dy), tdt[dtype])
+    Y = torch.zeros((B, Ho, Wo, C), dtype=tdt[dtype], device=DEV)
+    IDX = torch.zeros((B, Ho, Wo, C), dtype=torch.uint8, device=DEV)
+    _lib.call('capmi_maxpool3x3s2_fwd', p(X), p(Y), p(IDX), B, H, W, C, Ho, Wo, code[dtype], stream())
+    np.testing.assert_array_equal(host(Y), _nhwc(y))
+    np.testing.assert_array_equal(host(IDX), _nhwc(idx))
+    DX = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+    _lib.call('capmi_maxpool3x3s2_bwd', p(DY), p(IDX), p(DX), B, H, W, C, Ho, Wo, code[dtype], stream())
+    check(host(DX), _nhwc(dx), dtype, name='maxpool bwd')
+    # stem im2col + GEMM == conv on the NCHW feed
+    img = rng.uniform(0, 1, (2, 3, 20, 20)).astype(np.float32)
+    k, s, pad, Kpad = 7, 2, 3, 160
+    w = rnd(rng.standard_normal((8, 3, k, k)) * 0.1, dtype)
+    yc = O.conv2d_fwd(rnd(img.astype(np.float64), dtype), w, s, pad)
+    Ho, Wo = yc.shape[2:]
+    col = torch.zeros((2 * Ho * Wo, Kpad), dtype=tdt[dtype], device=DEV)
+    _lib.call('capmi_im2col_stem', p(dev(img, torch.float32)), p(col), 2, 3, 20, 20, k, s, pad, Ho, Wo, Kpad, code[dtype], stream())
+    wk = np.zeros((8, Kpad)); wk[:, :k * k * 3] = w.transpose(0, 2, 3, 1).reshape(8, -1)
+    Yc = torch.zeros((2 * Ho * Wo, 8), dtype=torch.float32, device=DEV)
+    _lib.call('capmi_igemm_nt', p(col), p(dev(wk, tdt[dtype])), p(Yc), _lib.gemm_geom(2 * Ho * Wo, Kpad), 8, Kpad, 8, None, None, 0,
+              None, 0, None, 0, 0, 1, code[dtype], stream())
+    check(host(Yc).reshape(2, Ho, Wo, 8), _nhwc(yc), dtype, name='stem conv')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('act,res', [('relu6', False), (None, True), ('relu', True), ('relu', False)])
+def test_batch_norm_chain(dtype, act, res):
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(7)
+    B, C, H, W = 3, 24, 5, 7
+    M = B * H * W
+    x = rnd(rng.standard_normal((B, C, H, W)) * 2 + 0.5, dtype)
+    r = rnd(rng.standard_normal((B, C, H, W)), dtype) if res else None
+    scale, offset = rng.uniform(0.5, 1.5, C), rng.standard_normal(C) * 0.2
+    rm, rv = rng.standard_normal(C), rng.uniform(0.5, 2, C)
+    y, saved, (nm, nv) = O.batch_norm_fwd(x, scale, offset, rm, rv)
+    pre = y + (r if res else 0)
+    out = O.relu6(pre) if act == 'relu6' else O.relu(pre) if act == 'relu' else pre
+    dout = rnd(rng.standard_normal(x.shape), dtype)
+    dz = O.relu6_bwd(dout, pre) if act == 'relu6' else O.relu_bwd(dout, out) if act == 'relu' else dout
+    dx, dscale, doffset = O.batch_norm_bwd(dz, saved, scale)
+    f32 = torch.float32
+    X = dev(_nhwc(x), tdt[dtype])
+    stats = torch.zeros(2 * C, dtype=f32, device=DEV)
+    _lib.call('capmi_bn_stats', p(X), M, C, p(stats), code[dtype], stream())
+    SC, OF, RM, RV = dev(scale, f32), dev(offset, f32), dev(rm, f32), dev(rv, f32)
+    mean, invstd, ca, cb = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(4))
+    _lib.call('capmi_bn_finalize', p(stats), M, C, p(SC), p(OF), p(RM), p(RV), 0.9, 1e-5, p(mean), p(invstd), p(ca), p(cb), 1, stream())
+    check(host(RM), nm, 'f32', name='running mean')
+    check(host(RV), nv, 'f32', name='running var')
+    R = dev(_nhwc(r), tdt[dtype]) if res else None
+    Y = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+    ac = _lib.ACT_CODES[act]
+    _lib.call('capmi_bn_apply', p(X), p(ca), p(cb), p(R), p(Y), M, C, ac, code[dtype], stream())
+    check(host(Y), _nhwc(out), dtype, name='bn apply')
+    # backward uses the stored (rounded) output for the activation mask, as the engine does
+    Yexact = dev(_nhwc(out), tdt[dtype])
+    DY = dev(_nhwc(dout), tdt[dtype])
+    red = torch.zeros(2 * C, dtype=f32, device=DEV)
+    _lib.call('capmi_bn_bwd_reduce', p(DY), p(X), p(Yexact), p(mean), p(invstd), p(red), M, C, ac, code[dtype], stream())
+    rr = host(red)
+    check(rr[:C], doffset, dtype, scale=np.abs(dz).sum((0, 2, 3)).max(), name='d offset')
+    check(rr[C:], dscale, dtype, scale=np.abs(dz).sum((0, 2, 3)).max(), name='d scale')
+    DX = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+    DR = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV) if res else None
+    _lib.call('capmi_bn_bwd_apply', p(DY), p(X), p(Yexact), p(mean), p(invstd), p(SC), p(red), p(DX), 0, p(DR), 0, M, C, ac, code[dtype], stream())
+    check(host(DX), _nhwc(dx), dtype, name='bn dx')
+    if res:
+        check(host(DR), _nhwc(dz), dtype, name='d residual')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_lstm_cell_sentinel_embedding(dtype):
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(11)
+    B, H, E, V = 5, 32, 16, 50
+    gates = rnd(rng.standard_normal((B, 4 * H)), dtype)
+    c_prev = rnd(rng.standard_normal((B, H)), dtype)
+    i, f, o, g = (O.sigmoid(gates[:, :H]), O.sigmoid(gates[:, H:2 * H]), O.sigmoid(gates[:, 2 * H:3 * H]), np.tanh(gates[:, 3 * H:]))
+    c = f * c_prev + i * g
+    h = o * np.tanh(c)
+    G, CP = dev(gates, tdt[dtype]), dev(c_prev, tdt[dtype])
+    Hn, Cn = (torch.zeros((B, H), dtype=tdt[dtype], device=DEV) for _ in range(2))
+    _lib.call('capmi_lstm_cell_fwd', p(G), p(CP), p(Hn), p(Cn), B, H, code[dtype], stream())
+    check(host(Hn), h, dtype, name='lstm h')
+    check(host(Cn), c, dtype, name='lstm c')
+    dh, dc = rnd(rng.standard_normal((B, H)), dtype), rnd(rng.standard_normal((B, H)), dtype)
+    cr = rnd(c, dtype)
+    tc = np.tanh(cr)
+    dct = dc + dh * o * (1 - tc ** 2)
+    want = np.concatenate([dct * g * i * (1 - i), dct * c_prev * f * (1 - f), dh * tc * o * (1 - o), dct * i * (1 - g * g)], 1)
+    DG = torch.zeros((B, 4 * H), dtype=tdt[dtype], device=DEV)
+    old = rnd(rng.standard_normal((B, H)), dtype)
+    DCP = dev(old, tdt[dtype])
+    _lib.call('capmi_lstm_cell_bwd', p(G), p(CP), p(dev(cr, tdt[dtype])), p(dev(dh, tdt[dtype])), p(dev(dc, tdt[dtype])), p(DG), p(DCP), 1,
+              B, H, code[dtype], stream())
+    check(host(DG), want, dtype, name='lstm dgates')
+    check(host(DCP), old + dct * f, dtype, name='lstm dc_prev (accumulate)')
+    # sentinel
+    sgpre = rnd(rng.standard_normal((B, H)), dtype)
+    S = torch.zeros((B, H), dtype=tdt[dtype], device=DEV)
+    _lib.call('capmi_sentinel_fwd', p(dev(sgpre, tdt[dtype])), p(dev(cr, tdt[dtype])), p(S), B * H, code[dtype], stream())
+    check(host(S), O.sigmoid(sgpre) * tc, dtype, name='sentinel')
+    ds = rnd(rng.standard_normal((B, H)), dtype)
+    D1, D2 = (torch.zeros((B, H), dtype=tdt[dtype], device=DEV) for _ in range(2))
+    _lib.call('capmi_sentinel_bwd', p(dev(ds, tdt[dtype])), p(dev(sgpre, tdt[dtype])), p(dev(cr, tdt[dtype])), p(D1), p(D2), B * H, code[dtype], stream())
+    sg = O.sigmoid(sgpre)
+    check(host(D1), ds * tc * sg * (1 - sg), dtype, name='sentinel dsg')
+    check(host(D2), ds * sg * (1 - tc ** 2), dtype, name='sentinel dc')
+    # embedding with padding rows, strided output
+    table = rnd(rng.standard_normal((V, E)), dtype)
+    ids = rng.randint(0, V, size=13).astype(np.int64)
+    ids[[2, 7]] = 0
+    out = torch.full((13, E + 8), 7.0, dtype=tdt[dtype], device=DEV)
+    IDS = torch.as_tensor(ids, device=DEV)
+    _lib.call('capmi_embedding_fwd', p(IDS), p(dev(table, tdt[dtype])), p(out), 13, E, V, E + 8, 0, code[dtype], stream())
+    check(host(out)[:, :E], O.embedding_fwd(ids, table, 0), dtype, name='embedding fwd')
+    assert np.all(host(out)[:, E:] == 7.0)
+    dout = rnd(rng.standard_normal((13, E + 8)), dtype)
+    DT = torch.zeros((V, E), dtype=torch.float32, device=DEV)
+    _lib.call('capmi_embedding_bwd', p(IDS), p(dev(dout, tdt[dtype])), p(DT), 13, E, V, E + 8, 0, code[dtype], stream())
+    check(host(DT), O.embedding_bwd(dout[:, :E], ids, (V, E), 0), dtype, name='embedding bwd')
+
+
+def _attn_ref(Ve, Vt, q, se, s, pp, w10, b10, T, B, K, H, slots):
+    """Oracle of one attention call, rows time-major; returns out, alpha."""
+    M = T * B
+    out = np.zeros((M, H)); alpha = np.ones((M, K + 1))
+    for m in range(M):
+        b = m % B
+        ctx_all = np.concatenate([Vt[b], s[m][None]], 0)
+        if slots:
+            z = np.tanh(np.concatenate([Ve[b], se[m][None]], 0) + q[m][None])
+            e = z @ w10 + b10
+            a = np.exp(e - e.max()); a /= a.sum()
+            alpha[m] = a
+        out[m] = (ctx_all * alpha[m][:, None]).mean(0) + pp[m]
+    return out, alpha
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('slots', [0, 1])
+def test_attention_fwd_bwd(dtype, slots):
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(5 + slots)
+    T, B, K, H = 3, 4, 9, 64
+    M = T * B
+    mk = lambda *s: rnd(rng.standard_normal(s) * 0.7, dtype)
+    Ve, Vt = mk(B, K, H), mk(B, K, H)
+    q, se, s, pp, dout = mk(M, H), mk(M, H), mk(M, H), mk(M, H), mk(M, H)
+    w10, b10 = mk(H), np.array([0.3])
+    out, alpha = _attn_ref(Ve, Vt, q, se, s, pp, w10, b10[0], T, B, K, H, slots)
+    t = lambda a: dev(a, tdt[dtype])
+    f32 = torch.float32
+    dVe_, dVt_, dq_, dse_, ds_, out_ = (torch.zeros(sh, dtype=tdt[dtype], device=DEV) for sh in
+                                        [(B, K, H), (B, K, H), (M, H), (M, H), (M, H), (M, H)])
+    alpha_, de_ = torch.zeros((M, K + 1), dtype=f32, device=DEV), torch.zeros((M, K + 1), dtype=f32, device=DEV)
+    tVe, tVt, tq, tse, ts, tp, tw, tb = t(Ve), t(Vt), t(q), t(se), t(s), t(pp), t(w10), dev(b10, f32)
+    _lib.call('capmi_ada_attention_fwd', p(tVe), p(tVt), p(tq), p(tse), p(ts), p(tp), p(tw), p(tb), p(out_), p(alpha_), T, B, K, H, slots,
+              code[dtype], stream())
+    check(host(out_), out, dtype, name='attention out')
+    if slots:
+        check(host(alpha_), alpha, dtype, name='alpha')
+    # backward reference via torch autograd (float64)
+    tt = lambda a: torch.tensor(a, dtype=torch.float64, requires_grad=True)
+    aVe, aVt, aq, ase, as_, aw, ab = tt(Ve), tt(Vt), tt(q), tt(se), tt(s), tt(w10), tt(b10)
+    bidx = torch.arange(M) % B
+    ctx_all = torch.cat([aVt[bidx], as_[:, None]], 1)
+    if slots:
+        z = torch.tanh(torch.cat([aVe[bidx], ase[:, None]], 1) + aq[:, None])
+        al = torch.softmax(z @ aw + ab, dim=1)
+    else:
+        al = torch.ones(M, K + 1, dtype=torch.float64)
+    o = (ctx_all * al[:, :, None]).mean(1)
+    (o * torch.tensor(dout)).sum().backward()
+    dw10_, db10_ = torch.zeros(H, dtype=f32, device=DEV), torch.zeros(1, dtype=f32, device=DEV)
+    _lib.call('capmi_ada_attention_bwd', p(tVe), p(tVt), p(tq), p(tse), p(ts), p(tw), p(alpha_), p(t(dout)), p(ds_), p(dVt_), p(dVe_), p(dq_),
+              p(dse_), p(dw10_), p(db10_), p(de_), T, B, K, H, slots, code[dtype], stream())
+    check(host(ds_), as_.grad.numpy(), dtype, name='ds')
+    check(host(dVt_), aVt.grad.numpy(), dtype, name='dVt')
+    if slots:
+        check(host(dVe_), aVe.grad.numpy(), dtype, name='dVe')
+        check(host(dq_), aq.grad.numpy(), dtype, name='dq')
+        check(host(dse_), ase.grad.numpy(), dtype, name='dse')
+        check(host(dw10_), aw.grad.numpy(), dtype, name='dw10')
+        check(host(db10_), ab.grad.numpy(), dtype, scale=1.0, name='db10')
+
+
+@pytest.mark.parametrize('V', [50, 1000, 12295])
+def test_softmax_xent_argmax(V):
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(V)
+    M, ld = 37, (V + 7) // 8 * 8
+    logits = np.zeros((M, ld), np.float32)
+    logits[:, :V] = rng.standard_normal((M, V)).astype(np.float32) * 3
+    tgt = rng.randint(1, V, size=M).astype(np.int64)
+    tgt[::5] = 0
+    ce, sm = O.softmax_with_cross_entropy_fwd(logits[:, :V].astype(np.float64), tgt)
+    mask = (tgt != 0)
+    want_loss = (ce[:, 0] * mask).sum() / mask.sum()
+    f32 = torch.float32
+    L, TG = dev(logits, f32), torch.as_tensor(tgt, device=DEV)
+    rl, lse, loss, cnt = (torch.zeros(n, dtype=f32, device=DEV) for n in (M, M, 1, 1))
+    _lib.call('capmi_softmax_xent_fwd', p(L), p(TG), p(rl), p(lse), M, V, ld, 0, stream())
+    _lib.call('capmi_xent_finalize', p(rl), p(TG), p(loss), p(cnt), M, 0, stream())
+    assert abs(host(loss)[0] - want_loss) < 1e-5 * max(1, abs(want_loss))
+    assert host(cnt)[0] == mask.sum()
+    for dtype in ('f32', 'bf16'):
+        D = torch.full((M, ld), 3.0, dtype=tdt[dtype], device=DEV)
+        _lib.call('capmi_softmax_xent_bwd', p(L), p(TG), p(lse), p(cnt), p(D), M, V, ld, ld, 0, code[dtype], stream())
+        want = O.softmax_with_cross_entropy_bwd((mask / mask.sum())[:, None], sm, tgt)
+        got = host(D)
+        check(got[:, :V], want, dtype, scale=1.0 / mask.sum(), name='dlogits')
+        assert np.all(got[:, V:] == 0)
+    # argmax with ties -> lowest index
+    logits[3, :V] = 0.0
+    logits[4, 7] = logits[4, 19] = 99.0
+    L = dev(logits, f32)
+    ids = torch.zeros(M, dtype=torch.int64, device=DEV)
+    idf = torch.zeros((M, 6), dtype=f32, device=DEV)
+    _lib.call('capmi_argmax', p(L), p(ids), p(idf) + 8, 6, M, V, ld, stream())
+    want = logits[:, :V].argmax(1)
+    np.testing.assert_array_equal(host(ids).astype(np.int64), want)
+    np.testing.assert_array_equal(host(idf)[:, 2].astype(np.int64), want)
+    assert want[3] == 0 and want[4] == 7
+
+
+def test_adam_paddle_form_and_shadows():
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(1)
+    n = 1003
+    pv, g, m, v = (rng.standard_normal(n).astype(np.float32) for _ in range(4))
+    v = np.abs(v)
+    f32 = torch.float32
+    P, G, Mm, Vv = dev(pv, f32), dev(g, f32), dev(m, f32), dev(v, f32)
+    from myimagecaptioningmodel_amd.optim import adam_lr_t
+    _lib.call('capmi_adam', p(P), p(G), p(Mm), p(Vv), n, adam_lr_t(1e-3, 3), 0.9, 0.999, 1e-8, 0.0, 0.5, stream())
+    # oracle: step counter 3, gradient pre-scaled by 1/2 (two ranks)
+    po, mo, vo = O.adam_update(pv.astype(np.float64), 0.5 * g.astype(np.float64), m.astype(np.float64), v.astype(np.float64), 1e-3, 3)
+    np.testing.assert_allclose(host(P), po, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(Mm), mo, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(host(Vv), vo, rtol=1e-5, atol=1e-7)
+    # clip
+    P2, M2, V2 = dev(pv, f32), dev(m, f32), dev(v, f32)
+    _lib.call('capmi_adam', p(P2), p(G), p(M2), p(V2), n, adam_lr_t(1e-3, 1), 0.9, 0.999, 1e-8, 0.1, 1.0, stream())
+    po, _, _ = O.adam_update(pv.astype(np.float64), g.astype(np.float64), m.astype(np.float64), v.astype(np.float64), 1e-3, 1, clip=0.1)
+    np.testing.assert_allclose(host(P2), po, rtol=1e-5, atol=1e-6)
