@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- train images/sec of the captioning hot path on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload = BASELINE.json configs[1]: ResNet-50 encoder + 512-d attention-LSTM decoder,
+vocab 10 000, 224x224, seq_len 20, batch 64 per GPU, bf16 storage / f32 accumulate.  One step =
+feed (device-resident synthetic batch) -> forward -> backward -> gradient all-reduce (N > 1) ->
+Paddle-form Adam -> weight-shadow refresh.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOAD = dict(encoder='resnet50', image_size=224, hidden=512, embed=512, vocab=10000, sentence_length=20,
+                infer_max_length=20, attention='slots', dtype='bf16', learning_rate=5e-5, encoder_trainable=True)
+PER_GPU_BATCH = 64
+
+
+def synthetic_batch(B, cfg, seed):
+    """uniform [0,1) images; captions <start>=2, U{L/2..L-2} content tokens in
+    [4,V), <stop>=3, <pad>=0 (mirrors ai_challenge_tokenizer.py:81-86)."""
+    rng = np.random.RandomState(seed)
+    S, L, V = cfg['image_size'], cfg['sentence_length'], cfg['vocab']
+    image = rng.uniform(0, 1, (B, 3, S, S)).astype(np.float32)
+    cap = np.zeros((B, L), np.int64)
+    for b in range(B):
+        n = rng.randint(L // 2, L - 1)
+        cap[b, 0] = 2
+        cap[b, 1:1 + n] = rng.randint(4, V, size=n)
+        cap[b, 1 + n] = 3
+    return image, cap
+
+
+def cpu_baseline(cfg, budget_s=25.0):
+    """The NumPy oracle ('port' of the reference graph, not PaddlePaddle) timed on the host cores
+    on a bounded sample: whole train steps (fwd + bwd + Adam) of the SAME model at a small batch."""
+    from oracle import model as om
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    ocfg = om.default_cfg(**{k: cfg[k] for k in ('encoder', 'image_size', 'hidden', 'embed', 'vocab', 'sentence_length',
+                                                 'infer_max_length', 'attention')})
+    B = 2
+    params = om.init_params(ocfg, seed=0, dtype=np.float32)
+    m = om.OracleModel(ocfg, params)
+    image, cap = synthetic_batch(B, cfg, 1234)
+    t0 = time.time()
+    steps = 0
+    while True:
+        m.forward_train(image, cap)
+        g = m.backward()
+        m.adam_step(g, lr=cfg['learning_rate'])
+        steps += 1
+        if time.time() - t0 > budget_s or steps >= 3:
+            break
+    dt = time.time() - t0
+    return dict(value=round(B * steps / dt, 4), unit='images/sec', cores=int(cores), kind='port',
+                sample='%d train step(s) (fwd+bwd+Adam) of the same ResNet-50 captioning model at batch %d, fp32 NumPy oracle, %.1f s'
+                       % (steps, B, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='per-GPU batch (default: the BASELINE config)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from myimagecaptioningmodel_amd import default_cfg, dp, profiling
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+
+    pg, rank, world, local = dp.init_process_group_from_env()
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+    dev = 'cuda:%d' % local
+    torch.cuda.set_device(local)
+    B = args.batch
+    cfg = default_cfg(batch_size=B * world, sample_count=0, **WORKLOAD)
+    eng = CaptionEngine(cfg, device=dev, use_graph=not args.no_graph, process_group=pg)
+    trainer = dp.OverlappedTrainer(eng) if world > 1 else None
+    image, cap = synthetic_batch(B, cfg, 1234 + rank)
+    image_d = torch.as_tensor(image).to(dev)
+    cap_d = torch.as_tensor(cap).to(dev)
+
+    def step():
+        if trainer is not None:
+            return trainer.train_step(image_d, cap_d)
+        return eng.train_step(image_d, cap_d)
+
+    for _ in range(max(1, args.warmup)):      # >= 1: builds plans, captures the hipGraph
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.cpu()[0])
+    assert final_loss == final_loss, 'loss is NaN'           # the check of train.py:140-141
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        out = {
+            'metric': 'train images/sec (224x224, seq_len=20, vocab~10k)', 'value': round(B * world * args.steps / dt, 2),
+            'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: ResNet-50 (build-defined) + 512-d adaptive-attention LSTM decoder, '
+                                   'vocab 10000, 224x224, seq_len 20, E=H=512, attention=slots, random-init weights',
+                       'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
+                       'hipgraph': not args.no_graph},
+            'final_loss': round(final_loss, 4),
+        }
+    # ---- roofline of the dominant kernel: per-launch HIP-event timing of one eager step (rank 0, N = 1 only)
+    if rank == 0 and world == 1 and not args.no_roofline:
+        prog = eng._train[B]
+        stats = {}
+        for plan in (prog['fwd'], prog['bwd']):
+            for k, v in profiling.time_plan(plan, eng._stream(), repeats=2).items():
+                s = stats.setdefault(k, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+                for f in s:
+                    s[f] += v[f]
+        total_ms = sum(s['ms'] for s in stats.values())
+        top = sorted(stats.items(), key=lambda kv: -kv[1]['ms'])
+        name, s = top[0]
+        if s['flops'] > 0 and s['flops'] / max(s['bytes'], 1) > 300:      # above the bf16 ridge point (2.5 PF / 8 TB/s)
+            achieved = s['flops'] / (s['ms'] * 1e-3) / 1e12
+            peak = profiling.PEAK_MFMA_TFLOPS['bf16']
+            roof = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4))
+        else:
+            achieved = s['bytes'] / (s['ms'] * 1e-3) / 1e9
+            roof = dict(bound='hbm', achieved=round(achieved, 1), peak=profiling.PEAK_HBM_GBPS, unit='GB/s',
+                        frac=round(achieved / profiling.PEAK_HBM_GBPS, 4))
+        roof.update(kernel=name, traffic=None, avg_launch_us=round(s['ms'] / s['launches'] * 1e3, 2),
+                    share_of_step=round(s['ms'] / total_ms, 3),
+                    algorithmic_per_launch={'GFLOP': round(s['flops'] / s['launches'] / 1e9, 3),
+                                            'MB': round(s['bytes'] / s['launches'] / 1e6, 3)})
+        out['roofline'] = roof
+        out['kernel_breakdown_ms_per_step'] = {k: round(v['ms'] / 2, 3) for k, v in top[:8]}
+        flops_img = 26.18e9          # 6 x 4.363 GMAC fwd, GEMM-class ops only
+        out['model_mfma_frac'] = round(out['value'] * flops_img / (world * profiling.PEAK_MFMA_TFLOPS['bf16'] * 1e12), 4)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(cfg)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

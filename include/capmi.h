@@ -46,11 +46,14 @@ typedef struct {
  * data gradients; layers.fc / mul (IC/model/model_adaAttention_aic.py:24,52,53,89,90,99,102,
  * 104,107,115,196,198), the lstm_unit gate fc (:87-88) and the tied vocabulary projection
  * matmul(transpose_y=True) (:25), forward and data-gradient.
- * Epilogue, in order: (+ bias[n]) (+ addend[m][n]) -> optional per-column f32 sum / sum-of-
- * squares accumulation into stats[0..N) / stats[N..2N) (atomic; fused batch-norm statistics)
+ * Epilogue, in order: (+ bias[n]) (+ addend[m][n]) -> optional fused batch-norm statistics: for
+ * every block of capmi_igemm_nt_stats_part_rows(M,N,dtype) consecutive rows and every column the
+ * exact (mean, sum (v-mean)^2) of the f32 accumulators, stored to stats[part][N][2] (plain
+ * stores: deterministic, cancellation-free; merged by capmi_bn_finalize)
  * -> act -> (* act'(ysaved[m][n]) when dact != NONE: ysaved holds the forward OUTPUT of that
  * activation) -> store as `dtype`, or f32 when out_f32.
  * Requires Cin % (16/sizeof(elem)) == 0 and ldx, ldw likewise; N, M arbitrary. */
+int capmi_igemm_nt_stats_part_rows(int M, int N, int dtype);
 int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom* g,
                    int N, int ldw, int ldy,
                    const float* bias, const void* addend, int ld_addend,
@@ -88,16 +91,19 @@ int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, 
 
 /* Batch norm, train mode (fluid.layers.batch_norm, IC/model/MobileNetV2.py:112-117) over
  * x [M][C] (M = B*H*W), fused with relu/relu6 (:119) and the residual add (:123-124).
- *   bn_stats   : stats[0..C) += sum_m x, stats[C..2C) += sum_m x^2          (f32 atomics)
- *   bn_finalize: mean/biased var from stats and count M; writes saved_mean, saved_invstd,
+ *   bn_stats   : ws[part][C][2] = exact (mean, sum (x-mean)^2) of every block of
+ *                capmi_bn_stats_part_rows(M,C,dtype) rows (two passes over the block, no atomics)
+ *   bn_finalize: merges the parts (Chan's formula, f64) into mean / biased variance over M rows;
+ *                writes saved_mean, saved_invstd,
  *                coef_a = scale*invstd, coef_b = offset - mean*coef_a, and updates the running
  *                stats with momentum (run = m*run + (1-m)*batch)
  *   bn_apply   : y = act(coef_a*x + coef_b (+ res))
  *   bn_bwd_reduce: with dz = dy * act'(y): red[0..C) += sum dz, red[C..2C) += sum dz*xhat
  *   bn_bwd_apply : dx (+)= scale*invstd*(dz - red0/M - xhat*red1/M); optional dres (+)= dz;
  *                  dscale/doffset = red1/red0 are read by the optimizer straight from `red`. */
-int capmi_bn_stats(const void* x, int M, int C, float* stats, int dtype, void* stream);
-int capmi_bn_finalize(const float* stats, int M, int C, const float* scale, const float* offset,
+int capmi_bn_stats_part_rows(int M, int C, int dtype);
+int capmi_bn_stats(const void* x, int M, int C, float* ws, int dtype, void* stream);
+int capmi_bn_finalize(const float* ws, int part_rows, int M, int C, const float* scale, const float* offset,
                       float* run_mean, float* run_var, float momentum, float eps,
                       float* saved_mean, float* saved_invstd, float* coef_a, float* coef_b,
                       int update_running, void* stream);

@@ -40,7 +40,7 @@ SIGNATURES = {
     'capmi_maxpool3x3s2_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_maxpool3x3s2_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_bn_stats': [_p, _i, _i, _p, _i, _p],
-    'capmi_bn_finalize': [_p, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p],
+    'capmi_bn_finalize': [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p],
     'capmi_bn_apply': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_reduce': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_apply': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
@@ -74,6 +74,12 @@ class CapmiError(RuntimeError):
     pass
 
 
+# queries without a stream argument: name -> argument ctypes (return the part size, > 0)
+QUERIES = {
+    'capmi_igemm_nt_stats_part_rows': [_i, _i, _i],
+    'capmi_bn_stats_part_rows': [_i, _i, _i],
+}
+
 _lib = None
 
 
@@ -89,6 +95,10 @@ def lib():
         L.capmi_last_error.restype = ctypes.c_char_p
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the symbol is missing
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        for name, args in QUERIES.items():
+            fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = ctypes.c_int
         _lib = L

@@ -69,10 +69,13 @@ def resnet(depth):
         for bi in range(nb):
             name = 'res%d_%d' % (si + 2, bi + 1)
             stride = 2 if (bi == 0 and si > 0) else 1
+            # the projection shortcut is emitted FIRST: the add is folded into branch2c's bn_apply
+            # (encoder.py), which must find the shortcut already computed -- and, in backward,
+            # must have written the shortcut's gradient before branch1's backward reads it
+            sc = b.conv(name + '_branch1', x, cin, 4 * w, 1, stride, 0, 1, None) if bi == 0 else x
             a = b.conv(name + '_branch2a', x, cin, w, 1, 1, 0, 1, 'relu')
             m = b.conv(name + '_branch2b', a, w, w, 3, stride, 1, 1, 'relu')
             c = b.conv(name + '_branch2c', m, w, 4 * w, 1, 1, 0, 1, None)
-            sc = b.conv(name + '_branch1', x, cin, 4 * w, 1, stride, 0, 1, None) if bi == 0 else x
             x = b.add(sc, c, 'relu')
             cin = 4 * w
     return Encoder(b.ops, x, 2048, 32)

@@ -5,63 +5,114 @@
 #include "common.h"
 
 // ------------------------------------------------------------------ BN statistics
+// Statistics travel as "parts": for each block of `part_rows` consecutive rows and each channel
+// the exact (mean, M2 = sum (x-mean)^2) of that block -- ws[part][C][2] f32.  Parts are written
+// with plain stores by exactly one producer (deterministic, no atomics) and merged in f64 by
+// bn_finalize with Chan's formula: no E[x^2]-E[x]^2 cancellation anywhere.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int M, int C, float* stats, ColLayout L) {
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int M, int C, float* ws, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
-    __shared__ float s1[256 * VEC], s2[256 * VEC];
+    __shared__ float s1[256 * VEC];
     const int tid = threadIdx.x;
-    for (int i = tid; i < L.cpc * VEC; i += 256) { s1[i] = 0.f; s2[i] = 0.f; }
+    for (int i = tid; i < L.cpc * VEC; i += 256) s1[i] = 0.f;
     __syncthreads();
     const int cc = tid % L.cpc, rr = tid / L.cpc;
     const int chunk = blockIdx.y * L.cpc + cc;
     const bool active = rr < L.rp && chunk * VEC < C;
-    float a1[VEC], a2[VEC];
+    const int m_begin = blockIdx.x * L.rows_per_block;
+    const int m_end = min(M, m_begin + L.rows_per_block);
+    const float inv_n = 1.f / (float)(m_end - m_begin);
+    float acc[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { a1[v] = 0.f; a2[v] = 0.f; }
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
     if (active) {
-        const int m_begin = blockIdx.x * L.rows_per_block;
-        const int m_end = min(M, m_begin + L.rows_per_block);
         for (int m = m_begin + rr; m < m_end; m += L.rp) {
             Vec<T> xv = vload<T>(x + (int64_t)m * C + chunk * VEC);
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) { float f = xv.get(v); a1[v] += f; a2[v] += f * f; }
+            for (int v = 0; v < VEC; ++v) acc[v] += xv.get(v);
         }
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) { atomicAdd(&s1[cc * VEC + v], a1[v]); atomicAdd(&s2[cc * VEC + v], a2[v]); }
+        for (int v = 0; v < VEC; ++v) atomicAdd(&s1[cc * VEC + v], acc[v]);
     }
     __syncthreads();
-    for (int i = tid; i < L.cpc * VEC; i += 256) {
-        int c = blockIdx.y * L.cpc * VEC + i;
-        if (c < C) { atomicAdd(&stats[c], s1[i]); atomicAdd(&stats[C + c], s2[i]); }
+    float mean[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { mean[v] = s1[cc * VEC + v] * inv_n; acc[v] = 0.f; }
+    __syncthreads();
+    for (int i = tid; i < L.cpc * VEC; i += 256) s1[i] = 0.f;
+    __syncthreads();
+    if (active) {      // second pass over the block's rows (just read: L2-resident)
+        for (int m = m_begin + rr; m < m_end; m += L.rp) {
+            Vec<T> xv = vload<T>(x + (int64_t)m * C + chunk * VEC);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { float d = xv.get(v) - mean[v]; acc[v] += d * d; }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) atomicAdd(&s1[cc * VEC + v], acc[v]);
+    }
+    __syncthreads();
+    if (active && rr == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float* w = ws + ((int64_t)blockIdx.x * C + chunk * VEC + v) * 2;
+            w[0] = mean[v];
+            w[1] = s1[cc * VEC + v];
+        }
     }
 }
 
-extern "C" int capmi_bn_stats(const void* x, int M, int C, float* stats, int dtype, void* stream) {
-    CAPMI_CHECK(x && stats, "capmi_bn_stats: null pointer");
+extern "C" int capmi_bn_stats_part_rows(int M, int C, int dtype) {
+    int gx, gy;
+    return col_layout(M, C, dtype == CAPMI_F32 ? 4 : 8, &gx, &gy).rows_per_block;
+}
+
+extern "C" int capmi_bn_stats(const void* x, int M, int C, float* ws, int dtype, void* stream) {
+    CAPMI_CHECK(x && ws, "capmi_bn_stats: null pointer");
     CAPMI_DISPATCH(dtype, "capmi_bn_stats", {
         CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_stats: C=%d not a multiple of %d", C, Vec<T>::N);
         int gx, gy;
         ColLayout L = col_layout(M, C, Vec<T>::N, &gx, &gy);
-        hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, M, C, stats, L);
+        hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, M, C, ws, L);
     });
     CAPMI_LAUNCH_CHECK("capmi_bn_stats");
     return 0;
 }
 
-__global__ void bn_finalize_kernel(const float* stats, int M, int C, const float* scale, const float* offset,
-                                   float* run_mean, float* run_var, float momentum, float eps,
-                                   float* saved_mean, float* saved_invstd, float* coef_a, float* coef_b,
-                                   int update_running) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    // f64 for the E[x^2]-E[x]^2 cancellation; per-channel work is negligible
-    double mean = (double)stats[c] / M;
-    double var = (double)stats[C + c] / M - mean * mean;
-    if (var < 0) var = 0;
-    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+// One workgroup per 64 channels; 4 groups of threads stride over the parts, f64 merge in LDS.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int part_rows, int M, int C,
+                                                          const float* scale, const float* offset, float* run_mean, float* run_var,
+                                                          float momentum, float eps, float* saved_mean, float* saved_invstd,
+                                                          float* coef_a, float* coef_b, int update_running) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int nparts = (M + part_rows - 1) / part_rows;
+    double s = 0.0;
+    if (c < C)
+        for (int p = ty; p < nparts; p += 4) {
+            int n = min(part_rows, M - p * part_rows);
+            s += (double)n * (double)ws[((int64_t)p * C + c) * 2];
+        }
+    red[ty][tx] = s;
+    __syncthreads();
+    const double mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (double)M;
+    __syncthreads();
+    double m2 = 0.0;
+    if (c < C)
+        for (int p = ty; p < nparts; p += 4) {
+            int n = min(part_rows, M - p * part_rows);
+            const float* w = ws + ((int64_t)p * C + c) * 2;
+            double d = (double)w[0] - mean;
+            m2 += (double)w[1] + (double)n * d * d;
+        }
+    red[ty][tx] = m2;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    const double var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (double)M;      // biased
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     saved_mean[c] = (float)mean;
     saved_invstd[c] = invstd;
-    float a = scale[c] * invstd;
+    const float a = scale[c] * invstd;
     coef_a[c] = a;
     coef_b[c] = offset[c] - (float)mean * a;
     if (update_running) {
@@ -70,13 +121,14 @@ __global__ void bn_finalize_kernel(const float* stats, int M, int C, const float
     }
 }
 
-extern "C" int capmi_bn_finalize(const float* stats, int M, int C, const float* scale, const float* offset,
+extern "C" int capmi_bn_finalize(const float* ws, int part_rows, int M, int C, const float* scale, const float* offset,
                                  float* run_mean, float* run_var, float momentum, float eps,
                                  float* saved_mean, float* saved_invstd, float* coef_a, float* coef_b,
                                  int update_running, void* stream) {
-    CAPMI_CHECK(stats && scale && offset && saved_mean && saved_invstd && coef_a && coef_b, "capmi_bn_finalize: null pointer");
+    CAPMI_CHECK(ws && scale && offset && saved_mean && saved_invstd && coef_a && coef_b, "capmi_bn_finalize: null pointer");
+    CAPMI_CHECK(part_rows > 0 && M > 0, "capmi_bn_finalize: bad part_rows/M");
     CAPMI_CHECK(!update_running || (run_mean && run_var), "capmi_bn_finalize: running stats missing");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, M, C, scale,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, ws, part_rows, M, C, scale,
                        offset, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, coef_b, update_running);
     CAPMI_LAUNCH_CHECK("capmi_bn_finalize");
     return 0;

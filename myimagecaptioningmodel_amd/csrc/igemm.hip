@@ -167,37 +167,80 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
     // ---- epilogue.  C/D layout: col = lane&15, row = (lane>>4)*4 + reg
     const T* addend = (const T*)a.addend;
     const T* ysaved = (const T*)a.ysaved;
+    const int wrow0 = m0 + wm * (BM / 2);                      // first row of this wave's sub-tile
+    const int wcnt = min(BM / 2, a.M - wrow0);                 // valid rows in it (<= 0: none)
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * (BN / 2) + j * 16 + fr;
         const bool cok = col < a.N;
         const float bias = (a.bias && cok) ? a.bias[col] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 16 + fg * 4 + r;
-                if (!(cok && row < a.M)) continue;
+                const int row = wrow0 + i * 16 + fg * 4 + r;
                 float v = acc[i][j][r] + bias;
-                if (addend) v += to_f32(addend[(int64_t)row * a.ld_addend + col]);
-                s1 += v;
-                s2 += v * v;
-                v = apply_act(v, a.act);
+                if (addend && cok && row < a.M) v += to_f32(addend[(int64_t)row * a.ld_addend + col]);
+                acc[i][j][r] = v;
+                if (row < a.M) s1 += v;
+            }
+        }
+        if (a.stats && wcnt > 0) {
+            // Fused batch-norm statistics, cancellation-free and deterministic: this wave's exact
+            // (mean, M2 = sum (v-mean)^2) of its BM/2-row block per column, taken from the f32
+            // accumulators in registers; bn_finalize merges the parts (Chan) in f64.
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            const float mean = s1 / (float)wcnt;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wrow0 + i * 16 + fg * 4 + r;
+                    const float d = acc[i][j][r] - mean;
+                    if (row < a.M) m2 += d * d;
+                }
+            m2 += __shfl_xor(m2, 16, 64); m2 += __shfl_xor(m2, 32, 64);
+            if (fg == 0 && cok) {
+                const int part = wrow0 / (BM / 2);
+                float* w = a.stats + ((int64_t)part * a.N + col) * 2;
+                w[0] = mean;
+                w[1] = m2;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wrow0 + i * 16 + fg * 4 + r;
+                if (!(cok && row < a.M)) continue;
+                float v = apply_act(acc[i][j][r], a.act);
                 if (a.dact) v *= act_grad_from_out(to_f32(ysaved[(int64_t)row * a.ld_saved + col]), a.dact);
                 if (a.out_f32) ((float*)a.y)[(int64_t)row * a.ldy + col] = v;
                 else ((T*)a.y)[(int64_t)row * a.ldy + col] = from_f32<T>(v);
             }
         }
-        if (a.stats) {     // fused batch-norm statistics: per-column sum / sum of squares
-            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (fg == 0 && cok) {
-                atomicAdd(&a.stats[col], s1);
-                atomicAdd(&a.stats[a.N + col], s2);
-            }
-        }
     }
+}
+
+// tile selection shared by the launcher and the statistics-workspace query
+static void nt_tile(int M, int N, int dtype, int* bm, int* bn) {
+    const bool wide = N > 64;
+    const bool tall = (int64_t)cdiv(M, 128) * cdiv(N, wide ? 128 : 64) >= 256;
+    if (dtype == CAPMI_BF16) {
+        *bm = tall ? 128 : 64;
+        *bn = wide ? 128 : 64;
+    } else {                      // f32 tiles are twice the bytes: stay under 64 KiB of static LDS
+        *bm = wide ? 64 : (tall ? 128 : 64);
+        *bn = wide ? 128 : 64;
+    }
+}
+
+extern "C" int capmi_igemm_nt_stats_part_rows(int M, int N, int dtype) {
+    int bm, bn;
+    nt_tile(M, N, dtype, &bm, &bn);
+    return bm / 2;
 }
 
 template <typename T, int BM, int BN>
@@ -227,16 +270,16 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
     a.g = *g; a.act = act; a.dact = dact; a.out_f32 = out_f32;
     CAPMI_CHECK(ldw >= a.K, "capmi_igemm_nt: ldw=%d < K=%d", ldw, a.K);
     hipStream_t st = (hipStream_t)stream;
-    const bool wide = N > 64;
-    const bool tall = (int64_t)cdiv(a.M, 128) * cdiv(N, wide ? 128 : 64) >= 256;
+    int bm, bn;
+    nt_tile(a.M, N, dtype, &bm, &bn);
     if (dtype == CAPMI_BF16) {
-        if (wide && tall) return launch_nt<bf16, 128, 128>(a, st);
-        if (wide) return launch_nt<bf16, 64, 128>(a, st);
-        if (tall) return launch_nt<bf16, 128, 64>(a, st);
+        if (bm == 128 && bn == 128) return launch_nt<bf16, 128, 128>(a, st);
+        if (bm == 64 && bn == 128) return launch_nt<bf16, 64, 128>(a, st);
+        if (bm == 128 && bn == 64) return launch_nt<bf16, 128, 64>(a, st);
         return launch_nt<bf16, 64, 64>(a, st);
-    } else if (dtype == CAPMI_F32) {   // f32 tiles are twice the bytes: stay under 64 KiB of static LDS
-        if (wide) return launch_nt<float, 64, 128>(a, st);
-        if (tall) return launch_nt<float, 128, 64>(a, st);
+    } else if (dtype == CAPMI_F32) {
+        if (bm == 64 && bn == 128) return launch_nt<float, 64, 128>(a, st);
+        if (bm == 128 && bn == 64) return launch_nt<float, 128, 64>(a, st);
         return launch_nt<float, 64, 64>(a, st);
     }
     capmi_set_error("capmi_igemm_nt: bad dtype %d", dtype);

@@ -13,7 +13,7 @@ weight-gradient GEMM (split over pixels, f32 atomics) -> data-gradient GEMM.
 import torch
 
 from . import arch
-from ._lib import ACT_CODES, ConvGeom, Plan, gemm_geom
+from ._lib import ACT_CODES, ConvGeom, Plan, gemm_geom, lib
 from .params import stem_kpad
 
 BN_MOMENTUM = 0.9      # fluid.layers.batch_norm defaults; MobileNetV2.py:112-117 overrides neither
@@ -41,10 +41,13 @@ class EncoderRunner:
         producer = {op.dst: op for op in enc.ops}
         self.fused_add = {}     # conv dst tensor id -> Add op folded into it
         self.skipped = set()
+        order = {id(op): i for i, op in enumerate(enc.ops)}
         for op in enc.ops:
             if isinstance(op, arch.Add):
                 pb = producer.get(op.b)
-                if isinstance(pb, arch.ConvBN) and pb.act is None and consumers.get(op.b, 0) == 1:
+                pa = producer.get(op.a)
+                a_ready = pa is None or pb is None or order[id(pa)] < order[id(pb)]   # operand a exists when b's bn_apply runs
+                if isinstance(pb, arch.ConvBN) and pb.act is None and consumers.get(op.b, 0) == 1 and a_ready:
                     self.fused_add[pb.dst] = op
                     self.skipped.add(id(op))
         # ---- shapes and buffers
@@ -63,9 +66,6 @@ class EncoderRunner:
         z = lambda shape, dt=None: torch.zeros(shape, dtype=dt or self.tdt, device=self.dev)
         self.act, self.grad, self.raw, self.bn = {}, {}, {}, {}
         self.pool_idx = {}
-        total_c = sum(op.cout for op in enc.ops if isinstance(op, arch.ConvBN))
-        self.stats = z((2 * total_c,), torch.float32)          # zeroed every step (fused BN statistics)
-        soff = 0
         max_elems = 0
         for op in enc.ops:
             if id(op) in self.skipped:
@@ -77,9 +77,16 @@ class EncoderRunner:
                 self.grad[out_id] = z((B, h, w, c))
             if isinstance(op, arch.ConvBN):
                 self.raw[op.dst] = z((B, h, w, c))
-                self.bn[op.dst] = dict(stats=self.stats[soff:soff + 2 * c], mean=z((c,), torch.float32),
+                # statistics workspace: (mean, M2) of every `part_rows`-row block, written by the conv
+                # epilogue (dense convs) or by bn_stats (depthwise); no zeroing needed
+                M = B * h * w
+                if op.groups > 1:
+                    part_rows = lib().capmi_bn_stats_part_rows(M, c, dtype_code)
+                else:
+                    part_rows = lib().capmi_igemm_nt_stats_part_rows(M, c, dtype_code)
+                nparts = (M + part_rows - 1) // part_rows
+                self.bn[op.dst] = dict(stats=z((nparts, c, 2), torch.float32), part_rows=part_rows, mean=z((c,), torch.float32),
                                        invstd=z((c,), torch.float32), a=z((c,), torch.float32), b=z((c,), torch.float32))
-                soff += 2 * c
                 max_elems = max(max_elems, B * h * w * c)
             elif isinstance(op, arch.MaxPool):
                 self.pool_idx[op.dst] = z((B, h, w, c), torch.uint8)
@@ -113,7 +120,6 @@ class EncoderRunner:
         """image: f32 NCHW [B,3,S,S] device tensor (the reference feed).  weights(name) -> tensor
         the kernels read (f32 master or bf16 shadow)."""
         st, B, code = self.store, self.B, self.code
-        plan.add('capmi_fill_f32', _p(self.stats), 0.0, self.stats.numel())
         for op in self.enc.ops:
             if id(op) in self.skipped:
                 continue
@@ -138,7 +144,7 @@ class EncoderRunner:
                     K = op.k * op.k * op.cin
                     plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
                              _p(bn['stats']), 0, 0, 0, code)
-                plan.add('capmi_bn_finalize', _p(bn['stats']), M, c, _p(st.view(op.name + '_bn_scale')),
+                plan.add('capmi_bn_finalize', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')),
                          _p(st.view(op.name + '_bn_offset')), _p(st.state[op.name + '_bn_mean']),
                          _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS, _p(bn['mean']), _p(bn['invstd']),
                          _p(bn['a']), _p(bn['b']), 1 if update_running else 0)

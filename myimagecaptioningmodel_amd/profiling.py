@@ -1,0 +1,97 @@
+"""Per-launch timing of a launch plan with HIP events, plus the algorithmic work model
+(FLOPs / HBM bytes per launch) used for the roofline line of bench.py.
+
+`time_plan` replays a Plan eagerly on the current stream and brackets every launch with a pair
+of events recorded on THAT stream, then groups by kernel label.  Labels follow the kernel
+symbol the C ABI entry dispatches to (tile shape included for the MFMA kernels) so they can be
+matched against `rocprofv3 --kernel-trace --stats` rows.
+"""
+import ctypes
+
+import torch
+
+from ._lib import BF16, ConvGeom
+
+# Peaks used as roofline denominators (/opt/skills/guides/MI355X_MICROARCH.md, chip-level table)
+PEAK_HBM_GBPS = 8000.0            # HBM3E spec; ~6300 measured achievable
+PEAK_MFMA_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}
+
+
+def _geom(arg):
+    g = arg
+    if isinstance(arg, ctypes._Pointer):
+        g = arg.contents
+    return g
+
+
+def _nt_tile(M, N, bf16):
+    wide = N > 64
+    tall = -(-M // 128) * -(-N // (128 if wide else 64)) >= 256
+    if bf16:
+        return (128, 128) if (wide and tall) else (64, 128) if wide else (128, 64) if tall else (64, 64)
+    return (64, 128) if wide else (128, 64) if tall else (64, 64)
+
+
+def describe(name, args):
+    """-> (label, flops, algorithmic_bytes) of one recorded launch."""
+    if name == 'capmi_igemm_nt':
+        g = _geom(args[3])
+        N, code, out_f32 = args[4], args[16], args[15]
+        M, K = g.B * g.Ho * g.Wo, g.kh * g.kw * g.Cin
+        es = 2 if code == BF16 else 4
+        bm, bn = _nt_tile(M, N, code == BF16)
+        # each input pixel / weight read once, output written once (im2col re-reads are on-chip)
+        nbytes = g.B * g.Hi * g.Wi * g.Cin * es + N * K * es + M * N * (4 if out_f32 else es)
+        if args[8]:
+            nbytes += M * N * es
+        if args[10]:
+            nbytes += M * N * es
+        return 'igemm_nt_kernel<%s,%d,%d>' % ('bf16' if code == BF16 else 'f32', bm, bn), 2.0 * M * N * K, nbytes
+    if name == 'capmi_igemm_tn_wgrad':
+        g = _geom(args[3])
+        N, code = args[4], args[7]
+        M, K = g.B * g.Ho * g.Wo, g.kh * g.kw * g.Cin
+        es = 2 if code == BF16 else 4
+        big = N >= 128 and K >= 128 and code == BF16
+        nbytes = g.B * g.Hi * g.Wi * g.Cin * es + M * N * es + N * K * 4
+        return 'igemm_tn_kernel<%s,%s>' % ('bf16' if code == BF16 else 'f32', '128,128' if big else '64,64'), 2.0 * M * N * K, nbytes
+    es_of = lambda code: 2 if code == BF16 else 4
+    if name == 'capmi_bn_apply':
+        M, C, code = args[5], args[6], args[8]
+        return 'bn_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[3] else 2)
+    if name == 'capmi_bn_stats':
+        return 'bn_stats_kernel', 0.0, args[1] * args[2] * es_of(args[4])
+    if name == 'capmi_bn_bwd_reduce':
+        M, C, act, code = args[6], args[7], args[8], args[9]
+        return 'bn_bwd_reduce_kernel', 0.0, M * C * es_of(code) * (3 if act else 2)
+    if name == 'capmi_bn_bwd_apply':
+        M, C, act, code = args[11], args[12], args[13], args[14]
+        n = 3 + (1 if act else 0) + (1 if args[9] else 0)
+        return 'bn_bwd_apply_kernel', 0.0, M * C * es_of(code) * n
+    return name.replace('capmi_', '') + '_kernel', 0.0, 0.0
+
+
+def time_plan(plan, stream_ptr, repeats=1):
+    """Returns {label: dict(ms, launches, flops, bytes)} for one (or `repeats`) eager replays."""
+    stats = {}
+    cur = torch.cuda.current_stream()
+    assert cur.cuda_stream == stream_ptr
+    for _ in range(repeats):
+        evs = []
+        for fn, name, args in plan.calls:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(cur)
+            rc = fn(*args, stream_ptr)
+            b.record(cur)
+            if rc != 0:
+                raise RuntimeError('%s failed during timing' % name)
+            evs.append((name, args, a, b))
+        torch.cuda.synchronize()
+        for name, args, a, b in evs:
+            label, fl, by = describe(name, args)
+            s = stats.setdefault(label, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+            s['ms'] += a.elapsed_time(b)
+            s['launches'] += 1
+            s['flops'] += fl
+            s['bytes'] += by
+    return stats

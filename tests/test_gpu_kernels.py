@@ -25,8 +25,16 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_KEEP = []      # device tensors passed as raw pointers must outlive the (asynchronous) launch
+
+
 def dev(a, dt):
-    return torch.as_tensor(np.ascontiguousarray(a)).to(device=DEV, dtype=dt)
+    t = torch.as_tensor(np.ascontiguousarray(a)).to(device=DEV, dtype=dt)
+    _KEEP.append(t)
+    if len(_KEEP) > 256:
+        torch.cuda.synchronize()
+        del _KEEP[:128]
+    return t
 
 
 def rnd(a, dtype):
@@ -71,14 +79,19 @@ def test_gemm_nt_epilogues(dtype, M, N, K):
     check(host(Y), np.tanh(a @ w.T + bias), dtype, name='bias+tanh')
     # addend + dact + f32 output + stats
     Y32 = torch.zeros((M, N), dtype=torch.float32, device=DEV)
-    stats = torch.zeros(2 * N, dtype=torch.float32, device=DEV)
+    pr = _lib.lib().capmi_igemm_nt_stats_part_rows(M, N, code[dtype])
+    nparts = (M + pr - 1) // pr
+    stats = torch.full((nparts * N * 2,), float('nan'), dtype=torch.float32, device=DEV)
     _lib.call('capmi_igemm_nt', p(A), p(W), p(Y32), g, N, K, N, None, p(dev(add, tdt[dtype])), N, p(dev(ysaved, tdt[dtype])), N,
               p(stats), 0, _lib.ACT_TANH, 1, code[dtype], stream())
     pre = a @ w.T + add
     check(host(Y32), pre * (1 - ysaved ** 2), dtype, name='addend+dact')
-    st = host(stats)
-    check(st[:N], pre.sum(0), dtype, scale=np.abs(pre).sum(0).max(), name='stats sum')
-    check(st[N:], (pre ** 2).sum(0), dtype, scale=(pre ** 2).sum(0).max(), name='stats sumsq')
+    # fused statistics: exact (mean, M2) per part of `pr` rows; merged here like bn_finalize does
+    st = host(stats).reshape(nparts, N, 2)
+    for pi in range(nparts):
+        blk = pre[pi * pr:(pi + 1) * pr]
+        check(st[pi, :, 0], blk.mean(0), dtype, name='part mean')
+        check(st[pi, :, 1], ((blk - blk.mean(0)) ** 2).sum(0), dtype, scale=(blk ** 2).sum(0).max(), name='part M2')
 
 
 def _nhwc(x):
@@ -216,11 +229,12 @@ def test_batch_norm_chain(dtype, act, res):
     dx, dscale, doffset = O.batch_norm_bwd(dz, saved, scale)
     f32 = torch.float32
     X = dev(_nhwc(x), tdt[dtype])
-    stats = torch.zeros(2 * C, dtype=f32, device=DEV)
+    pr = _lib.lib().capmi_bn_stats_part_rows(M, C, code[dtype])
+    stats = torch.full(((M + pr - 1) // pr * C * 2,), float('nan'), dtype=f32, device=DEV)
     _lib.call('capmi_bn_stats', p(X), M, C, p(stats), code[dtype], stream())
     SC, OF, RM, RV = dev(scale, f32), dev(offset, f32), dev(rm, f32), dev(rv, f32)
     mean, invstd, ca, cb = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(4))
-    _lib.call('capmi_bn_finalize', p(stats), M, C, p(SC), p(OF), p(RM), p(RV), 0.9, 1e-5, p(mean), p(invstd), p(ca), p(cb), 1, stream())
+    _lib.call('capmi_bn_finalize', p(stats), pr, M, C, p(SC), p(OF), p(RM), p(RV), 0.9, 1e-5, p(mean), p(invstd), p(ca), p(cb), 1, stream())
     check(host(RM), nm, 'f32', name='running mean')
     check(host(RV), nv, 'f32', name='running var')
     R = dev(_nhwc(r), tdt[dtype]) if res else None
@@ -242,6 +256,33 @@ def test_batch_norm_chain(dtype, act, res):
     check(host(DX), _nhwc(dx), dtype, name='bn dx')
     if res:
         check(host(DR), _nhwc(dz), dtype, name='d residual')
+
+
+def test_batch_norm_statistics_no_cancellation():
+    """mean >> std: a single-pass E[x^2]-E[x]^2 in f32 loses the variance entirely here."""
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(0)
+    M, C = 5000, 32
+    x = (100.0 + 1e-2 * rng.standard_normal((M, C))).astype(np.float32)
+    X = dev(x, torch.float32)
+    f32 = torch.float32
+    pr = _lib.lib().capmi_bn_stats_part_rows(M, C, _lib.F32)
+    ws = torch.zeros(((M + pr - 1) // pr * C * 2,), dtype=f32, device=DEV)
+    _lib.call('capmi_bn_stats', p(X), M, C, p(ws), _lib.F32, stream())
+    ones, zeros = torch.ones(C, dtype=f32, device=DEV), torch.zeros(C, dtype=f32, device=DEV)
+    mean, invstd, ca, cb = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(4))
+    _lib.call('capmi_bn_finalize', p(ws), pr, M, C, p(ones), p(zeros), None, None, 0.9, 1e-5, p(mean), p(invstd), p(ca), p(cb), 0, stream())
+    x64 = x.astype(np.float64)
+    np.testing.assert_allclose(host(mean), x64.mean(0), rtol=1e-6)
+    np.testing.assert_allclose(host(invstd), 1 / np.sqrt(x64.var(0) + 1e-5), rtol=1e-4)
+    # the same through the GEMM epilogue: x = A . I
+    eye = torch.eye(C, dtype=f32, device=DEV)
+    Y = torch.zeros((M, C), dtype=f32, device=DEV)
+    pr2 = _lib.lib().capmi_igemm_nt_stats_part_rows(M, C, _lib.F32)
+    ws2 = torch.zeros(((M + pr2 - 1) // pr2 * C * 2,), dtype=f32, device=DEV)
+    _lib.call('capmi_igemm_nt', p(X), p(eye), p(Y), _lib.gemm_geom(M, C), C, C, C, None, None, 0, None, 0, p(ws2), 0, 0, 0, _lib.F32, stream())
+    _lib.call('capmi_bn_finalize', p(ws2), pr2, M, C, p(ones), p(zeros), None, None, 0.9, 1e-5, p(mean), p(invstd), p(ca), p(cb), 0, stream())
+    np.testing.assert_allclose(host(invstd), 1 / np.sqrt(x64.var(0) + 1e-5), rtol=1e-4)
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
