@@ -93,25 +93,30 @@ int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, 
  * x [M][C] (M = B*H*W), fused with relu/relu6 (:119) and the residual add (:123-124).
  *   bn_stats   : ws[part][C][2] = exact (mean, sum (x-mean)^2) of every block of
  *                capmi_bn_stats_part_rows(M,C,dtype) rows (two passes over the block, no atomics)
- *   bn_finalize: merges the parts (Chan's formula, f64) into mean / biased variance over M rows;
- *                writes saved_mean, saved_invstd,
- *                coef_a = scale*invstd, coef_b = offset - mean*coef_a, and updates the running
+ *   bn_finalize: merges the parts (Chan's formula, f64; two levels when there are many -- ws must
+ *                have room for 32 extra parts: [ceil(M/part_rows) + 32][C][2]) into mean / biased
+ *                variance over M rows;
+ *                writes saved_mean, saved_invstd, coef_a = scale*invstd, and updates the running
  *                stats with momentum (run = m*run + (1-m)*batch)
- *   bn_apply   : y = act(coef_a*x + coef_b (+ res))
- *   bn_bwd_reduce: with dz = dy * act'(y): red[0..C) += sum dz, red[C..2C) += sum dz*xhat
+ *   bn_apply   : y = act(coef_a*(x - mean) + offset (+ res))   (mean subtracted first: a*x + b
+ *                with b = offset - a*mean would cancel when |mean| >> std)
+ *   bn_bwd_reduce: with dz = dy * act'(y): red[0..C) += sum dz, red[C..2C) += sum dz*xhat; two
+ *                stages through the partial-sum workspace ws (capmi_bn_bwd_ws_floats(M,C,dtype)
+ *                floats) -- no atomics, deterministic
  *   bn_bwd_apply : dx (+)= scale*invstd*(dz - red0/M - xhat*red1/M); optional dres (+)= dz;
  *                  dscale/doffset = red1/red0 are read by the optimizer straight from `red`. */
 int capmi_bn_stats_part_rows(int M, int C, int dtype);
 int capmi_bn_stats(const void* x, int M, int C, float* ws, int dtype, void* stream);
-int capmi_bn_finalize(const float* ws, int part_rows, int M, int C, const float* scale, const float* offset,
+int capmi_bn_finalize(float* ws, int part_rows, int M, int C, const float* scale,
                       float* run_mean, float* run_var, float momentum, float eps,
-                      float* saved_mean, float* saved_invstd, float* coef_a, float* coef_b,
+                      float* saved_mean, float* saved_invstd, float* coef_a,
                       int update_running, void* stream);
-int capmi_bn_apply(const void* x, const float* coef_a, const float* coef_b, const void* res, void* y,
-                   int M, int C, int act, int dtype, void* stream);
+int capmi_bn_apply(const void* x, const float* saved_mean, const float* coef_a, const float* offset,
+                   const void* res, void* y, int M, int C, int act, int dtype, void* stream);
+int capmi_bn_bwd_ws_floats(int M, int C, int dtype);
 int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y, const float* saved_mean,
-                        const float* saved_invstd, float* red, int M, int C, int act, int dtype,
-                        void* stream);
+                        const float* saved_invstd, float* ws, float* red, int M, int C, int act,
+                        int dtype, void* stream);
 int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, const float* saved_mean,
                        const float* saved_invstd, const float* scale, const float* red,
                        void* dx, int dx_accumulate, void* dres, int dres_accumulate,

@@ -40,9 +40,9 @@ SIGNATURES = {
     'capmi_maxpool3x3s2_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_maxpool3x3s2_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_bn_stats': [_p, _i, _i, _p, _i, _p],
-    'capmi_bn_finalize': [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _i, _p],
-    'capmi_bn_apply': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    'capmi_bn_bwd_reduce': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_bn_finalize': [_p, _i, _i, _i, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p],
+    'capmi_bn_apply': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_bn_bwd_reduce': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_apply': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     'capmi_add_act': [_p, _p, _p, _l, _i, _i, _p],
     'capmi_act_bwd': [_p, _p, _p, _i, _l, _i, _i, _p],
@@ -78,6 +78,7 @@ class CapmiError(RuntimeError):
 QUERIES = {
     'capmi_igemm_nt_stats_part_rows': [_i, _i, _i],
     'capmi_bn_stats_part_rows': [_i, _i, _i],
+    'capmi_bn_bwd_ws_floats': [_i, _i, _i],
 }
 
 _lib = None
@@ -87,6 +88,8 @@ def lib():
     """Loads libcapmi.so once; raises CapmiError when the extension is missing."""
     global _lib
     if _lib is None:
+        # torch first: libcapmi.so must bind to the HIP runtime torch brings (one runtime per process)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise CapmiError('libcapmi.so not found at %s -- run __graft_entry__.build() '
                              '(myimagecaptioningmodel_amd/csrc/build.sh); there is no fallback path' % LIB_PATH)

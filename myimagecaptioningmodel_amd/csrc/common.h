@@ -169,6 +169,42 @@ static ColLayout col_layout(int M, int C, int vec, int* grid_x, int* grid_y, int
 }
 
 
+// Sum the per-thread partials acc[VEC] of the (cc, rr) layout over rr.  `part` holds 256*VEC floats.
+// After the call threads with rr == 0 hold the block totals of their channel chunk in acc[].
+// Plain LDS stores + a strided re-read: no same-address atomic contention, fixed summation order.
+template <int VEC>
+__device__ __forceinline__ void block_col_reduce(float* part, float (&acc)[VEC], int cc, int rr, const ColLayout& L, bool active) {
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) part[(rr * L.cpc + cc) * VEC + v] = acc[v];
+    }
+    __syncthreads();
+    if (active && rr == 0) {
+        for (int r = 1; r < L.rp; ++r) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += part[(r * L.cpc + cc) * VEC + v];
+        }
+    }
+}
+
+// rows-per-thread-heavy variant of col_layout for the streaming (elementwise / reduce) kernels
+static ColLayout ew_layout(int M, int C, int vec, int* grid_x, int* grid_y) {
+    ColLayout L;
+    int chunks = C / vec;
+    L.cpc = chunks < 256 ? chunks : 256;
+    *grid_y = cdiv(chunks, L.cpc);
+    L.rp = 256 / L.cpc;
+    int target_blocks = 1024 / *grid_y;                 // ~4 workgroups per CU
+    if (target_blocks < 1) target_blocks = 1;
+    int rpb = cdiv(M, target_blocks);
+    rpb = cdiv(rpb, L.rp) * L.rp;
+    if (rpb < L.rp * 8) rpb = L.rp * 8;                 // >= 8 rows per thread amortise the setup
+    L.rows_per_block = rpb;
+    *grid_x = cdiv(M, rpb);
+    return L;
+}
+
 // grid for grid-stride elementwise kernels of n 16-byte chunks
 static inline int ew_grid(int64_t n) {
     int64_t b = (n + 255) / 256;

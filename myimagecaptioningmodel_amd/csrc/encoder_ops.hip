@@ -1,275 +1,8 @@
-// HBM-bound encoder kernels for gfx950: batch-norm (statistics, apply, backward), depthwise 3x3,
-// 3x3/s2 max pool, stem im2col and the elementwise glue.  All operate on NHWC tensors viewed as
+// HBM-bound encoder kernels for gfx950: depthwise 3x3, 3x3/s2 max pool, stem im2col and the
+// elementwise glue (batch norm lives in bn_ops.hip).  All operate on NHWC tensors viewed as
 // [M = B*H*W][C]; every global access is a 16-byte chunk (8 bf16 / 4 f32) of consecutive
 // channels, so a 64-lane wave touches 1 KiB of contiguous memory per instruction.
 #include "common.h"
-
-// ------------------------------------------------------------------ BN statistics
-// Statistics travel as "parts": for each block of `part_rows` consecutive rows and each channel
-// the exact (mean, M2 = sum (x-mean)^2) of that block -- ws[part][C][2] f32.  Parts are written
-// with plain stores by exactly one producer (deterministic, no atomics) and merged in f64 by
-// bn_finalize with Chan's formula: no E[x^2]-E[x]^2 cancellation anywhere.
-template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, int M, int C, float* ws, ColLayout L) {
-    constexpr int VEC = Vec<T>::N;
-    __shared__ float s1[256 * VEC];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < L.cpc * VEC; i += 256) s1[i] = 0.f;
-    __syncthreads();
-    const int cc = tid % L.cpc, rr = tid / L.cpc;
-    const int chunk = blockIdx.y * L.cpc + cc;
-    const bool active = rr < L.rp && chunk * VEC < C;
-    const int m_begin = blockIdx.x * L.rows_per_block;
-    const int m_end = min(M, m_begin + L.rows_per_block);
-    const float inv_n = 1.f / (float)(m_end - m_begin);
-    float acc[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-    if (active) {
-        for (int m = m_begin + rr; m < m_end; m += L.rp) {
-            Vec<T> xv = vload<T>(x + (int64_t)m * C + chunk * VEC);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] += xv.get(v);
-        }
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) atomicAdd(&s1[cc * VEC + v], acc[v]);
-    }
-    __syncthreads();
-    float mean[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) { mean[v] = s1[cc * VEC + v] * inv_n; acc[v] = 0.f; }
-    __syncthreads();
-    for (int i = tid; i < L.cpc * VEC; i += 256) s1[i] = 0.f;
-    __syncthreads();
-    if (active) {      // second pass over the block's rows (just read: L2-resident)
-        for (int m = m_begin + rr; m < m_end; m += L.rp) {
-            Vec<T> xv = vload<T>(x + (int64_t)m * C + chunk * VEC);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) { float d = xv.get(v) - mean[v]; acc[v] += d * d; }
-        }
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) atomicAdd(&s1[cc * VEC + v], acc[v]);
-    }
-    __syncthreads();
-    if (active && rr == 0) {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            float* w = ws + ((int64_t)blockIdx.x * C + chunk * VEC + v) * 2;
-            w[0] = mean[v];
-            w[1] = s1[cc * VEC + v];
-        }
-    }
-}
-
-extern "C" int capmi_bn_stats_part_rows(int M, int C, int dtype) {
-    int gx, gy;
-    return col_layout(M, C, dtype == CAPMI_F32 ? 4 : 8, &gx, &gy).rows_per_block;
-}
-
-extern "C" int capmi_bn_stats(const void* x, int M, int C, float* ws, int dtype, void* stream) {
-    CAPMI_CHECK(x && ws, "capmi_bn_stats: null pointer");
-    CAPMI_DISPATCH(dtype, "capmi_bn_stats", {
-        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_stats: C=%d not a multiple of %d", C, Vec<T>::N);
-        int gx, gy;
-        ColLayout L = col_layout(M, C, Vec<T>::N, &gx, &gy);
-        hipLaunchKernelGGL(bn_stats_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, M, C, ws, L);
-    });
-    CAPMI_LAUNCH_CHECK("capmi_bn_stats");
-    return 0;
-}
-
-// One workgroup per 64 channels; 4 groups of threads stride over the parts, f64 merge in LDS.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int part_rows, int M, int C,
-                                                          const float* scale, const float* offset, float* run_mean, float* run_var,
-                                                          float momentum, float eps, float* saved_mean, float* saved_invstd,
-                                                          float* coef_a, float* coef_b, int update_running) {
-    __shared__ double red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
-    const int nparts = (M + part_rows - 1) / part_rows;
-    double s = 0.0;
-    if (c < C)
-        for (int p = ty; p < nparts; p += 4) {
-            int n = min(part_rows, M - p * part_rows);
-            s += (double)n * (double)ws[((int64_t)p * C + c) * 2];
-        }
-    red[ty][tx] = s;
-    __syncthreads();
-    const double mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (double)M;
-    __syncthreads();
-    double m2 = 0.0;
-    if (c < C)
-        for (int p = ty; p < nparts; p += 4) {
-            int n = min(part_rows, M - p * part_rows);
-            const float* w = ws + ((int64_t)p * C + c) * 2;
-            double d = (double)w[0] - mean;
-            m2 += (double)w[1] + (double)n * d * d;
-        }
-    red[ty][tx] = m2;
-    __syncthreads();
-    if (ty != 0 || c >= C) return;
-    const double var = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (double)M;      // biased
-    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-    saved_mean[c] = (float)mean;
-    saved_invstd[c] = invstd;
-    const float a = scale[c] * invstd;
-    coef_a[c] = a;
-    coef_b[c] = offset[c] - (float)mean * a;
-    if (update_running) {
-        run_mean[c] = run_mean[c] * momentum + (float)mean * (1.f - momentum);
-        run_var[c] = run_var[c] * momentum + (float)var * (1.f - momentum);
-    }
-}
-
-extern "C" int capmi_bn_finalize(const float* ws, int part_rows, int M, int C, const float* scale, const float* offset,
-                                 float* run_mean, float* run_var, float momentum, float eps,
-                                 float* saved_mean, float* saved_invstd, float* coef_a, float* coef_b,
-                                 int update_running, void* stream) {
-    CAPMI_CHECK(ws && scale && offset && saved_mean && saved_invstd && coef_a && coef_b, "capmi_bn_finalize: null pointer");
-    CAPMI_CHECK(part_rows > 0 && M > 0, "capmi_bn_finalize: bad part_rows/M");
-    CAPMI_CHECK(!update_running || (run_mean && run_var), "capmi_bn_finalize: running stats missing");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, ws, part_rows, M, C, scale,
-                       offset, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, coef_b, update_running);
-    CAPMI_LAUNCH_CHECK("capmi_bn_finalize");
-    return 0;
-}
-
-// ------------------------------------------------------------------ BN apply (+residual, +act)
-template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ ca,
-                                                       const float* __restrict__ cb, const T* __restrict__ res,
-                                                       T* __restrict__ y, int64_t nchunks, int cpr, int act) {
-    constexpr int VEC = Vec<T>::N;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
-        int c0 = (int)(e % cpr) * VEC;
-        Vec<T> xv = vload<T>(x + e * VEC), rv, ov;
-        if (res) rv = vload<T>(res + e * VEC);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            float f = ca[c0 + v] * xv.get(v) + cb[c0 + v];
-            if (res) f += rv.get(v);
-            ov.set(v, apply_act(f, act));
-        }
-        vstore<T>(y + e * VEC, ov);
-    }
-}
-
-extern "C" int capmi_bn_apply(const void* x, const float* coef_a, const float* coef_b, const void* res, void* y,
-                              int M, int C, int act, int dtype, void* stream) {
-    CAPMI_CHECK(x && coef_a && coef_b && y, "capmi_bn_apply: null pointer");
-    CAPMI_DISPATCH(dtype, "capmi_bn_apply", {
-        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_apply: C=%d not a multiple of %d", C, Vec<T>::N);
-        int64_t n = (int64_t)M * C / Vec<T>::N;
-        hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)x, coef_a,
-                           coef_b, (const T*)res, (T*)y, n, C / Vec<T>::N, act);
-    });
-    CAPMI_LAUNCH_CHECK("capmi_bn_apply");
-    return 0;
-}
-
-// ------------------------------------------------------------------ BN backward
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                            const T* __restrict__ y, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, float* red, int M, int C,
-                                                            int act, ColLayout L) {
-    constexpr int VEC = Vec<T>::N;
-    __shared__ float s1[256 * VEC], s2[256 * VEC];
-    const int tid = threadIdx.x;
-    for (int i = tid; i < L.cpc * VEC; i += 256) { s1[i] = 0.f; s2[i] = 0.f; }
-    __syncthreads();
-    const int cc = tid % L.cpc, rr = tid / L.cpc;
-    const int chunk = blockIdx.y * L.cpc + cc;
-    const bool active = rr < L.rp && chunk * VEC < C;
-    if (active) {
-        float a1[VEC], a2[VEC], mu[VEC], is[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) { a1[v] = 0.f; a2[v] = 0.f; mu[v] = mean[chunk * VEC + v]; is[v] = invstd[chunk * VEC + v]; }
-        const int m_begin = blockIdx.x * L.rows_per_block;
-        const int m_end = min(M, m_begin + L.rows_per_block);
-        for (int m = m_begin + rr; m < m_end; m += L.rp) {
-            const int64_t off = (int64_t)m * C + chunk * VEC;
-            Vec<T> dv = vload<T>(dy + off), xv = vload<T>(x + off), yv;
-            if (act) yv = vload<T>(y + off);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                float dz = dv.get(v);
-                if (act) dz *= act_grad_from_out(yv.get(v), act);
-                a1[v] += dz;
-                a2[v] += dz * (xv.get(v) - mu[v]) * is[v];
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) { atomicAdd(&s1[cc * VEC + v], a1[v]); atomicAdd(&s2[cc * VEC + v], a2[v]); }
-    }
-    __syncthreads();
-    for (int i = tid; i < L.cpc * VEC; i += 256) {
-        int c = blockIdx.y * L.cpc * VEC + i;
-        if (c < C) { atomicAdd(&red[c], s1[i]); atomicAdd(&red[C + c], s2[i]); }
-    }
-}
-
-extern "C" int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y, const float* saved_mean,
-                                   const float* saved_invstd, float* red, int M, int C, int act, int dtype,
-                                   void* stream) {
-    CAPMI_CHECK(dy && x && saved_mean && saved_invstd && red, "capmi_bn_bwd_reduce: null pointer");
-    CAPMI_CHECK(!act || y, "capmi_bn_bwd_reduce: activation mask needs y");
-    CAPMI_DISPATCH(dtype, "capmi_bn_bwd_reduce", {
-        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_bwd_reduce: C=%d not a multiple of %d", C, Vec<T>::N);
-        int gx, gy;
-        ColLayout L = col_layout(M, C, Vec<T>::N, &gx, &gy);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
-                           (const T*)x, (const T*)y, saved_mean, saved_invstd, red, M, C, act, L);
-    });
-    CAPMI_LAUNCH_CHECK("capmi_bn_bwd_reduce");
-    return 0;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                           const T* __restrict__ y, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, const float* __restrict__ scale,
-                                                           const float* __restrict__ red, T* dx, int dx_acc, T* dres,
-                                                           int dres_acc, int64_t nchunks, int cpr, int C, float inv_m, int act) {
-    constexpr int VEC = Vec<T>::N;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
-        const int c0 = (int)(e % cpr) * VEC;
-        Vec<T> dv = vload<T>(dy + e * VEC), xv = vload<T>(x + e * VEC), yv, ov, rv, dxo, dro;
-        if (act) yv = vload<T>(y + e * VEC);
-        if (dx_acc) dxo = vload<T>(dx + e * VEC);
-        if (dres && dres_acc) dro = vload<T>(dres + e * VEC);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            const int c = c0 + v;
-            float dz = dv.get(v);
-            if (act) dz *= act_grad_from_out(yv.get(v), act);
-            float xhat = (xv.get(v) - mean[c]) * invstd[c];
-            float g = scale[c] * invstd[c] * (dz - red[c] * inv_m - xhat * red[C + c] * inv_m);
-            if (dx_acc) g += dxo.get(v);
-            ov.set(v, g);
-            if (dres) rv.set(v, dres_acc ? dz + dro.get(v) : dz);
-        }
-        vstore<T>(dx + e * VEC, ov);
-        if (dres) vstore<T>(dres + e * VEC, rv);
-    }
-}
-
-extern "C" int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, const float* saved_mean,
-                                  const float* saved_invstd, const float* scale, const float* red, void* dx,
-                                  int dx_accumulate, void* dres, int dres_accumulate, int M, int C, int act, int dtype,
-                                  void* stream) {
-    CAPMI_CHECK(dy && x && saved_mean && saved_invstd && scale && red && dx, "capmi_bn_bwd_apply: null pointer");
-    CAPMI_CHECK(!act || y, "capmi_bn_bwd_apply: activation mask needs y");
-    CAPMI_DISPATCH(dtype, "capmi_bn_bwd_apply", {
-        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_bwd_apply: C=%d not a multiple of %d", C, Vec<T>::N);
-        int64_t n = (int64_t)M * C / Vec<T>::N;
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)dy,
-                           (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, red, (T*)dx, dx_accumulate,
-                           (T*)dres, dres_accumulate, n, C / Vec<T>::N, C, 1.f / (float)M, act);
-    });
-    CAPMI_LAUNCH_CHECK("capmi_bn_bwd_apply");
-    return 0;
-}
 
 // ------------------------------------------------------------------ elementwise glue
 template <typename T>

@@ -85,12 +85,18 @@ class EncoderRunner:
                 else:
                     part_rows = lib().capmi_igemm_nt_stats_part_rows(M, c, dtype_code)
                 nparts = (M + part_rows - 1) // part_rows
-                self.bn[op.dst] = dict(stats=z((nparts, c, 2), torch.float32), part_rows=part_rows, mean=z((c,), torch.float32),
-                                       invstd=z((c,), torch.float32), a=z((c,), torch.float32), b=z((c,), torch.float32))
+                self.bn[op.dst] = dict(stats=z((nparts + 32, c, 2), torch.float32), part_rows=part_rows, mean=z((c,), torch.float32),
+                                       invstd=z((c,), torch.float32), a=z((c,), torch.float32))
                 max_elems = max(max_elems, B * h * w * c)
             elif isinstance(op, arch.MaxPool):
                 self.pool_idx[op.dst] = z((B, h, w, c), torch.uint8)
         self.draw = z((max_elems,)) if need_backward else None          # grad w.r.t. a conv's raw output (scratch)
+        ws = 0
+        for op in enc.ops:
+            if isinstance(op, arch.ConvBN):
+                h, w, c = self.shape[op.dst]
+                ws = max(ws, lib().capmi_bn_bwd_ws_floats(B * h * w, c, dtype_code))
+        self.bwd_ws = z((ws,), torch.float32) if need_backward else None  # partial sums of bn_bwd_reduce (scratch)
         stem = enc.ops[0]
         h, w, _ = self.shape[stem.dst]
         self.kpad = stem_kpad(stem.k, stem.cin)
@@ -145,15 +151,15 @@ class EncoderRunner:
                     plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
                              _p(bn['stats']), 0, 0, 0, code)
                 plan.add('capmi_bn_finalize', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')),
-                         _p(st.view(op.name + '_bn_offset')), _p(st.state[op.name + '_bn_mean']),
-                         _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS, _p(bn['mean']), _p(bn['invstd']),
-                         _p(bn['a']), _p(bn['b']), 1 if update_running else 0)
+                         _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS,
+                         _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0)
+                offset = _p(st.view(op.name + '_bn_offset'))
                 fa = self.fused_add.get(op.dst)
                 if fa is None:
-                    plan.add('capmi_bn_apply', _p(raw), _p(bn['a']), _p(bn['b']), None, _p(self.act[op.dst]), M, c,
+                    plan.add('capmi_bn_apply', _p(raw), _p(bn['mean']), _p(bn['a']), offset, None, _p(self.act[op.dst]), M, c,
                              ACT_CODES[op.act], code)
                 else:
-                    plan.add('capmi_bn_apply', _p(raw), _p(bn['a']), _p(bn['b']), _p(self.act[fa.a]), _p(self.act[fa.dst]),
+                    plan.add('capmi_bn_apply', _p(raw), _p(bn['mean']), _p(bn['a']), offset, _p(self.act[fa.a]), _p(self.act[fa.dst]),
                              M, c, ACT_CODES[fa.act], code)
             elif isinstance(op, arch.Add):
                 n = self.act[op.dst].numel()
@@ -186,7 +192,7 @@ class EncoderRunner:
                 dy, y = self.grad[out_id], self.act[out_id]
                 red = st.gview(op.name + '_bn_offset')        # [d offset | d scale] adjacent in the flat buffer
                 assert c % 8 == 0 and st.entries[op.name + '_bn_scale'].offset == st.entries[op.name + '_bn_offset'].offset + c
-                plan.add('capmi_bn_bwd_reduce', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']), _p(red), M, c, act, code)
+                plan.add('capmi_bn_bwd_reduce', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']), _p(self.bwd_ws), _p(red), M, c, act, code)
                 dres, dres_acc = None, 0
                 if fa is not None and fa.a != 0:
                     dres = self.grad[fa.a]

@@ -57,12 +57,12 @@ def describe(name, args):
         return 'igemm_tn_kernel<%s,%s>' % ('bf16' if code == BF16 else 'f32', '128,128' if big else '64,64'), 2.0 * M * N * K, nbytes
     es_of = lambda code: 2 if code == BF16 else 4
     if name == 'capmi_bn_apply':
-        M, C, code = args[5], args[6], args[8]
-        return 'bn_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[3] else 2)
+        M, C, code = args[6], args[7], args[9]
+        return 'bn_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[4] else 2)
     if name == 'capmi_bn_stats':
         return 'bn_stats_kernel', 0.0, args[1] * args[2] * es_of(args[4])
     if name == 'capmi_bn_bwd_reduce':
-        M, C, act, code = args[6], args[7], args[8], args[9]
+        M, C, act, code = args[7], args[8], args[9], args[10]
         return 'bn_bwd_reduce_kernel', 0.0, M * C * es_of(code) * (3 if act else 2)
     if name == 'capmi_bn_bwd_apply':
         M, C, act, code = args[11], args[12], args[13], args[14]

@@ -83,9 +83,16 @@ def test_gemm_nt_epilogues(dtype, M, N, K):
     nparts = (M + pr - 1) // pr
     stats = torch.full((nparts * N * 2,), float('nan'), dtype=torch.float32, device=DEV)
     _lib.call('capmi_igemm_nt', p(A), p(W), p(Y32), g, N, K, N, None, p(dev(add, tdt[dtype])), N, p(dev(ysaved, tdt[dtype])), N,
-              p(stats), 0, _lib.ACT_TANH, 1, code[dtype], stream())
+              None, 0, _lib.ACT_TANH, 1, code[dtype], stream())
     pre = a @ w.T + add
     check(host(Y32), pre * (1 - ysaved ** 2), dtype, name='addend+dact')
+    # in-place accumulate (y == addend), as the recurrent gate GEMM and the data-gradient sums use it
+    Yacc = dev(add, tdt[dtype]).clone()
+    _lib.call('capmi_igemm_nt', p(A), p(W), p(Yacc), g, N, K, N, None, p(Yacc), N, None, 0, None, 0, 0, 0, code[dtype], stream())
+    check(host(Yacc), pre, dtype, name='in-place addend')
+    _lib.call('capmi_igemm_nt', p(A), p(W), p(Y32), g, N, K, N, p(dev(bias, torch.float32)), None, 0, None, 0,
+              p(stats), 0, 0, 1, code[dtype], stream())
+    pre = a @ w.T + bias
     # fused statistics: exact (mean, M2) per part of `pr` rows; merged here like bn_finalize does
     st = host(stats).reshape(nparts, N, 2)
     for pi in range(nparts):
@@ -230,23 +237,24 @@ def test_batch_norm_chain(dtype, act, res):
     f32 = torch.float32
     X = dev(_nhwc(x), tdt[dtype])
     pr = _lib.lib().capmi_bn_stats_part_rows(M, C, code[dtype])
-    stats = torch.full(((M + pr - 1) // pr * C * 2,), float('nan'), dtype=f32, device=DEV)
+    stats = torch.full((((M + pr - 1) // pr + 32) * C * 2,), float('nan'), dtype=f32, device=DEV)
     _lib.call('capmi_bn_stats', p(X), M, C, p(stats), code[dtype], stream())
     SC, OF, RM, RV = dev(scale, f32), dev(offset, f32), dev(rm, f32), dev(rv, f32)
-    mean, invstd, ca, cb = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(4))
-    _lib.call('capmi_bn_finalize', p(stats), pr, M, C, p(SC), p(OF), p(RM), p(RV), 0.9, 1e-5, p(mean), p(invstd), p(ca), p(cb), 1, stream())
+    mean, invstd, ca = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(3))
+    _lib.call('capmi_bn_finalize', p(stats), pr, M, C, p(SC), p(RM), p(RV), 0.9, 1e-5, p(mean), p(invstd), p(ca), 1, stream())
     check(host(RM), nm, 'f32', name='running mean')
     check(host(RV), nv, 'f32', name='running var')
     R = dev(_nhwc(r), tdt[dtype]) if res else None
     Y = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
     ac = _lib.ACT_CODES[act]
-    _lib.call('capmi_bn_apply', p(X), p(ca), p(cb), p(R), p(Y), M, C, ac, code[dtype], stream())
+    _lib.call('capmi_bn_apply', p(X), p(mean), p(ca), p(OF), p(R), p(Y), M, C, ac, code[dtype], stream())
     check(host(Y), _nhwc(out), dtype, name='bn apply')
     # backward uses the stored (rounded) output for the activation mask, as the engine does
     Yexact = dev(_nhwc(out), tdt[dtype])
     DY = dev(_nhwc(dout), tdt[dtype])
     red = torch.zeros(2 * C, dtype=f32, device=DEV)
-    _lib.call('capmi_bn_bwd_reduce', p(DY), p(X), p(Yexact), p(mean), p(invstd), p(red), M, C, ac, code[dtype], stream())
+    bws = torch.zeros(_lib.lib().capmi_bn_bwd_ws_floats(M, C, code[dtype]), dtype=f32, device=DEV)
+    _lib.call('capmi_bn_bwd_reduce', p(DY), p(X), p(Yexact), p(mean), p(invstd), p(bws), p(red), M, C, ac, code[dtype], stream())
     rr = host(red)
     check(rr[:C], doffset, dtype, scale=np.abs(dz).sum((0, 2, 3)).max(), name='d offset')
     check(rr[C:], dscale, dtype, scale=np.abs(dz).sum((0, 2, 3)).max(), name='d scale')
@@ -267,21 +275,25 @@ def test_batch_norm_statistics_no_cancellation():
     X = dev(x, torch.float32)
     f32 = torch.float32
     pr = _lib.lib().capmi_bn_stats_part_rows(M, C, _lib.F32)
-    ws = torch.zeros(((M + pr - 1) // pr * C * 2,), dtype=f32, device=DEV)
+    ws = torch.zeros((((M + pr - 1) // pr + 32) * C * 2,), dtype=f32, device=DEV)
     _lib.call('capmi_bn_stats', p(X), M, C, p(ws), _lib.F32, stream())
     ones, zeros = torch.ones(C, dtype=f32, device=DEV), torch.zeros(C, dtype=f32, device=DEV)
-    mean, invstd, ca, cb = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(4))
-    _lib.call('capmi_bn_finalize', p(ws), pr, M, C, p(ones), p(zeros), None, None, 0.9, 1e-5, p(mean), p(invstd), p(ca), p(cb), 0, stream())
+    mean, invstd, ca = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(3))
+    _lib.call('capmi_bn_finalize', p(ws), pr, M, C, p(ones), None, None, 0.9, 1e-5, p(mean), p(invstd), p(ca), 0, stream())
     x64 = x.astype(np.float64)
     np.testing.assert_allclose(host(mean), x64.mean(0), rtol=1e-6)
     np.testing.assert_allclose(host(invstd), 1 / np.sqrt(x64.var(0) + 1e-5), rtol=1e-4)
+    Yn = torch.zeros((M, C), dtype=f32, device=DEV)
+    _lib.call('capmi_bn_apply', p(X), p(mean), p(ca), p(zeros), None, p(Yn), M, C, 0, _lib.F32, stream())
+    want = (x64 - x64.mean(0)) / np.sqrt(x64.var(0) + 1e-5)
+    assert np.abs(host(Yn) - want).max() < 2e-3          # x itself carries only ~4 digits below the mean
     # the same through the GEMM epilogue: x = A . I
     eye = torch.eye(C, dtype=f32, device=DEV)
     Y = torch.zeros((M, C), dtype=f32, device=DEV)
     pr2 = _lib.lib().capmi_igemm_nt_stats_part_rows(M, C, _lib.F32)
-    ws2 = torch.zeros(((M + pr2 - 1) // pr2 * C * 2,), dtype=f32, device=DEV)
+    ws2 = torch.zeros((((M + pr2 - 1) // pr2 + 32) * C * 2,), dtype=f32, device=DEV)
     _lib.call('capmi_igemm_nt', p(X), p(eye), p(Y), _lib.gemm_geom(M, C), C, C, C, None, None, 0, None, 0, p(ws2), 0, 0, 0, _lib.F32, stream())
-    _lib.call('capmi_bn_finalize', p(ws2), pr2, M, C, p(ones), p(zeros), None, None, 0.9, 1e-5, p(mean), p(invstd), p(ca), p(cb), 0, stream())
+    _lib.call('capmi_bn_finalize', p(ws2), pr2, M, C, p(ones), None, None, 0.9, 1e-5, p(mean), p(invstd), p(ca), 0, stream())
     np.testing.assert_allclose(host(invstd), 1 / np.sqrt(x64.var(0) + 1e-5), rtol=1e-4)
 
 
