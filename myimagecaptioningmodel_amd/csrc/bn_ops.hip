@@ -261,17 +261,31 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
 }
 
-// one workgroup per 64 entries of the [2C] vector, 4 thread groups stride over the partial rows
+// one workgroup per 16 entries of the [2C] vector; 16 thread groups stride over the partial rows
+// with 8 independent loads in flight each (the partials are L2-resident: this is latency, not bytes)
 __global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* __restrict__ ws, int nblocks, int n2c, float* red) {
-    __shared__ float s[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int j = blockIdx.x * 64 + tx;
+    __shared__ float s[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + tx;
     float acc = 0.f;
-    if (j < n2c)
-        for (int b = ty; b < nblocks; b += 4) acc += ws[(int64_t)b * n2c + j];
+    if (j < n2c) {
+        int b = ty;
+        for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = ws[(int64_t)(b + u * 16) * n2c + j];
+            acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+        }
+        for (; b < nblocks; b += 16) acc += ws[(int64_t)b * n2c + j];
+    }
     s[ty][tx] = acc;
     __syncthreads();
-    if (ty == 0 && j < n2c) red[j] += (s[0][tx] + s[1][tx]) + (s[2][tx] + s[3][tx]);
+    if (ty == 0 && j < n2c) {
+        float tot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tot += s[r][tx];
+        red[j] += tot;
+    }
 }
 
 static ColLayout bwd_reduce_layout(int M, int C, int vec, int* gx, int* gy) {
@@ -303,12 +317,14 @@ extern "C" int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y,
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)x,
                            (const T*)y, saved_mean, saved_invstd, ws, M, C, act, L);
     });
-    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(cdiv(2 * C, 64)), dim3(256), 0, (hipStream_t)stream, ws, gx, 2 * C, red);
+    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(cdiv(2 * C, 16)), dim3(256), 0, (hipStream_t)stream, ws, gx, 2 * C, red);
     CAPMI_LAUNCH_CHECK("capmi_bn_bwd_reduce");
     return 0;
 }
 
-// dx (+)= k1*dz + k2*(x - mu) + k3,  k1 = s*is, k2 = -s*is^2*red1/M, k3 = -k1*red0/M;  dres (+)= dz
+// dx (+)= k1 * ((dz - m0) - (x - mu)*c2),  k1 = s*is, m0 = red0/M, c2 = is*red1/M;  dres (+)= dz.
+// Both differences are formed BEFORE scaling: a spatially uniform dz (e.g. the reference's
+// singleton attention) makes dz - mean(dz) cancel almost completely.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -318,15 +334,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int cc = threadIdx.x % L.cpc, rr = threadIdx.x / L.cpc;
     const int chunk = blockIdx.y * L.cpc + cc;
     if (rr >= L.rp || chunk * VEC >= C) return;
-    float k1[VEC], k2[VEC], k3[VEC], mu[VEC];
+    float k1[VEC], c2[VEC], m0[VEC], mu[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         const int c = chunk * VEC + v;
         const float is = invstd[c], s = scale[c];
         mu[v] = mean[c];
         k1[v] = s * is;
-        k2[v] = -s * is * is * red[C + c] * inv_m;
-        k3[v] = -k1[v] * red[c] * inv_m;
+        c2[v] = is * red[C + c] * inv_m;
+        m0[v] = red[c] * inv_m;
     }
     const int m_begin = blockIdx.x * L.rows_per_block;
     const int m_end = min(M, m_begin + L.rows_per_block);
@@ -341,7 +357,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         for (int v = 0; v < VEC; ++v) {
             float dz = dv.get(v);
             if (act) dz *= act_grad_from_out(yv.get(v), act);
-            float g = k1[v] * dz + k2[v] * (xv.get(v) - mu[v]) + k3[v];
+            float g = k1[v] * ((dz - m0[v]) - (xv.get(v) - mu[v]) * c2[v]);
             if (dx_acc) g += dxo.get(v);
             ov.set(v, g);
             if (dres) rv.set(v, dres_acc ? dz + dro.get(v) : dz);

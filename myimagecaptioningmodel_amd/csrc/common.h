@@ -109,6 +109,27 @@ __device__ __forceinline__ float act_grad_from_out(float y, int act) {
     }
 }
 
+// ------------------------------------------------------------------ LDS-only workgroup barrier
+// __syncthreads() is a full workgroup fence: it also waits (s_waitcnt vmcnt(0)) until every global
+// store the wave has issued is complete.  Where only LDS data is handed between waves, wait for the
+// LDS counter alone so global stores stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Sum of x over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), result in every lane.
+// VALU only (v_permlane32_swap / v_permlane16_swap, gfx950): no LDS crossbar, no lgkmcnt wait.
+__device__ __forceinline__ float row4_sum(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);     // a[0] = lower half everywhere, a[1] = upper half
+    float y = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    unsigned w = __builtin_bit_cast(unsigned, y);
+    auto b = __builtin_amdgcn_permlane16_swap(w, w, false, false);     // b[0] = even rows everywhere, b[1] = odd rows
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
 // ------------------------------------------------------------------ reductions (wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

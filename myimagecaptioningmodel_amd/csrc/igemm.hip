@@ -137,38 +137,141 @@ template <> __device__ __forceinline__ void store8<float>(float* p, const float 
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (each with a private L2).  Remap the launch
+// index so that every XCD gets a CONTIGUOUS run of tiles: tiles that share input rows / write
+// the two halves of the same output rows then meet in one L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// TN consecutive output values of one row -> one vector store (bf16: 4/8 bytes, f32: 8/16 bytes)
+template <typename O, int TN> __device__ __forceinline__ void store_run(O* p, const float (&v)[TN]) {
+    if constexpr (sizeof(O) == 2) {
+        if constexpr (TN == 4) {
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *reinterpret_cast<bf16x4*>(p) = o;
+        } else {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            bf16x2 o = {(bf16)v[0], (bf16)v[1]};
+            *reinterpret_cast<bf16x2*>(p) = o;
+        }
+    } else {
+        if constexpr (TN == 4) *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        else {
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            *reinterpret_cast<f32x2*>(p) = f32x2{v[0], v[1]};
+        }
+    }
+}
+template <typename O, int TN> __device__ __forceinline__ void load_run(const O* p, float (&v)[TN]) {
+    if constexpr (sizeof(O) == 2) {
+        if constexpr (TN == 4) {
+            bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)o[e];
+        } else {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+            bf16x2 o = *reinterpret_cast<const bf16x2*>(p);
+            v[0] = (float)o[0]; v[1] = (float)o[1];
+        }
+    } else {
+        if constexpr (TN == 4) {
+            f32x4 o = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = o[e];
+        } else {
+            typedef __attribute__((ext_vector_type(2))) float f32x2;
+            f32x2 o = *reinterpret_cast<const f32x2*>(p);
+            v[0] = o[0]; v[1] = o[1];
+        }
+    }
+}
+template <int TN> __device__ __forceinline__ void act_run(float (&v)[TN], int act) {
+    switch (act) {
+        case CAPMI_ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < TN; ++e) v[e] = fmaxf(v[e], 0.f);
+            break;
+        case CAPMI_ACT_RELU6:
+#pragma unroll
+            for (int e = 0; e < TN; ++e) v[e] = fminf(fmaxf(v[e], 0.f), 6.f);
+            break;
+        case CAPMI_ACT_TANH:
+#pragma unroll
+            for (int e = 0; e < TN; ++e) v[e] = tanhf_(v[e]);
+            break;
+        case CAPMI_ACT_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < TN; ++e) v[e] = sigmoidf_(v[e]);
+            break;
+        default: break;
+    }
+}
+template <int TN> __device__ __forceinline__ void dact_run(float (&v)[TN], const float (&y)[TN], int dact) {
+    switch (dact) {
+        case CAPMI_ACT_RELU:
+#pragma unroll
+            for (int e = 0; e < TN; ++e) v[e] = y[e] > 0.f ? v[e] : 0.f;
+            break;
+        case CAPMI_ACT_RELU6:
+#pragma unroll
+            for (int e = 0; e < TN; ++e) v[e] = (y[e] > 0.f && y[e] < 6.f) ? v[e] : 0.f;
+            break;
+        case CAPMI_ACT_TANH:
+#pragma unroll
+            for (int e = 0; e < TN; ++e) v[e] *= 1.f - y[e] * y[e];
+            break;
+        case CAPMI_ACT_SIGMOID:
+#pragma unroll
+            for (int e = 0; e < TN; ++e) v[e] *= y[e] * (1.f - y[e]);
+            break;
+        default: break;
+    }
+}
+
 // ------------------------------------------------------------------ NT kernel
+// Column permutation: the weight row fed to MFMA tile j, lane fr of a wave is column TN*fr + j of
+// the wave's BN/2-column range (the permutation is applied when the W tile is written to LDS, so
+// fragment reads keep their conflict-free addresses).  Each lane then owns TN CONSECUTIVE output
+// columns of every row it holds: the epilogue stores straight from registers -- a wave instruction
+// writes 4 rows x (16 lanes x TN values) = whole 128-byte lines (bf16, TN = 4), no LDS round trip.
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
-    constexpr int BK = 32;
+    // BK = 64 with ONE LDS stage + one stage in registers: the next tile's 16-byte loads (8 per
+    // thread for a 128x128 tile) are in flight during the whole compute phase.  The small-K convs
+    // are bound by memory concurrency (bytes in flight per CU), not by MFMA or LDS.
+    constexpr int BK = 64;
     constexpr int VEC = Vec<T>::N;
     constexpr int CPR = BK / VEC;          // 16-byte chunks per tile row
     constexpr int LD = BK + VEC;           // padded LDS row, elements (16-byte aligned rows)
     constexpr int RSTEP = 256 / CPR;
     constexpr int ACH = BM / RSTEP, BCH = BN / RSTEP;
     constexpr int TM = BM / 32, TN = BN / 32;
-    constexpr int EPI_LD = BN + 4;                                     // f32 words per epilogue row
-    constexpr int STAGE_BYTES = 2 * (BM + BN) * LD * (int)sizeof(T);
-    constexpr int EPI_BYTES = (BM / 2) * EPI_LD * 4;
-    constexpr int SMEM_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
-    T* As = reinterpret_cast<T*>(smem);                // [2][BM*LD]
-    T* Bs = As + 2 * BM * LD;                          // [2][BN*LD]
-    float* epi = reinterpret_cast<float*>(smem);       // [BM/2][EPI_LD], reuses the staging space
+    constexpr int WN = BN / 2;             // columns per wave
+    __shared__ __attribute__((aligned(16))) T As[BM * LD];
+    __shared__ __attribute__((aligned(16))) T Bs[BN * LD];
 
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ W = (const T*)a.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (a.N + BN - 1) / BN;
-    const int m0 = (blockIdx.x / tiles_n) * BM;
-    const int n0 = (blockIdx.x % tiles_n) * BN;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
     const int kc = tid % CPR, r0 = tid / CPR;
 
     RowPos rp[ACH];
 #pragma unroll
     for (int i = 0; i < ACH; ++i) rp[i] = row_pos(m0 + r0 + i * RSTEP, a.M, a.g);
     KPos kp = k_pos(kc * VEC, a.g);
+    int brow[BCH];                         // permuted LDS row of each W row this thread stages
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+        const int nl = r0 + i * RSTEP, rem = nl % WN;
+        brow[i] = (nl / WN) * WN + (rem % TN) * 16 + rem / TN;
+    }
 
     Vec<T> ra[ACH], rb[BCH];
     auto load_tile = [&]() {          // loads the tile at the current kp, then advances kp by BK
@@ -184,11 +287,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
         }
         k_advance(kp, BK, a.g);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < ACH; ++i) vstore<T>(&As[buf * BM * LD + (r0 + i * RSTEP) * LD + kc * VEC], ra[i]);
+        for (int i = 0; i < ACH; ++i) vstore<T>(&As[(r0 + i * RSTEP) * LD + kc * VEC], ra[i]);
 #pragma unroll
-        for (int i = 0; i < BCH; ++i) vstore<T>(&Bs[buf * BN * LD + (r0 + i * RSTEP) * LD + kc * VEC], rb[i]);
+        for (int i = 0; i < BCH; ++i) vstore<T>(&Bs[brow[i] * LD + kc * VEC], rb[i]);
     };
 
     f32x4 acc[TM][TN];
@@ -198,114 +301,116 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nkt = (a.K + BK - 1) / BK;
-    load_tile();
-    store_tile(0);
-    __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
+    load_tile();
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) load_tile();
-        Frag<T> af[TM], bf[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) af[i].load(&As[buf * BM * LD + (wm * (BM / 2) + i * 16 + fr) * LD + fg * 8]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j].load(&Bs[buf * BN * LD + (wn * (BN / 2) + j * 16 + fr) * LD + fg * 8]);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) mma16(acc[i][j], af[i], bf[j]);
-        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        if (kt) __syncthreads();                 // every wave is done reading the previous tile
+        store_tile();
         __syncthreads();
+        if (kt + 1 < nkt) load_tile();           // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            Frag<T> af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i].load(&As[(wm * (BM / 2) + i * 16 + fr) * LD + ks * 32 + fg * 8]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j].load(&Bs[(wn * WN + j * 16 + fr) * LD + ks * 32 + fg * 8]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mma16(acc[i][j], af[i], bf[j]);
+        }
     }
 
-    // ---- epilogue, phase 1 (registers).  C/D layout: col = lane&15, row = (lane>>4)*4 + reg.
-    // bias, then the fused batch-norm statistics of this wave's BM/2-row block.
+    // ---- epilogue (registers only).  acc[i][j][r] = output (row wrow0 + 16i + 4fg + r, column col0 + j).
     const int wrow0 = m0 + wm * (BM / 2);                      // first row of this wave's sub-tile
     const int wcnt = min(BM / 2, a.M - wrow0);                 // valid rows in it (<= 0: none)
+    const int col0 = n0 + wn * WN + TN * fr;                   // this lane's TN consecutive columns
+    const bool rows_full = wcnt == BM / 2;
+    if (a.bias) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * (BN / 2) + j * 16 + fr;
-        const bool cok = col < a.N;
-        const float bias = (a.bias && cok) ? a.bias[col] : 0.f;
-        float s1 = 0.f;
+        for (int j = 0; j < TN; ++j) {
+            const float bias = col0 + j < a.N ? a.bias[col0 + j] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[i][j][r] += bias;
-                if (wrow0 + i * 16 + fg * 4 + r < a.M) s1 += acc[i][j][r];
-            }
-        if (a.stats && wcnt > 0) {
-            // exact (mean, M2 = sum (v-mean)^2) per column from the f32 accumulators; plain stores,
-            // one producer per (part, column): deterministic, cancellation-free (see bn_ops.hip)
-            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-            const float mean = s1 / (float)wcnt;
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += bias;
+        }
+    }
+    if (a.stats && wcnt > 0) {
+        // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) of this wave's BM/2-row block
+        // per column, from the f32 accumulators; plain stores, one producer per (part, column):
+        // deterministic and cancellation-free (merged by bn_finalize, bn_ops.hip).
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rows_full || i * 16 + fg * 4 + r < wcnt) s1 += acc[i][j][r];
+            const float mean = row4_sum(s1) / (float)wcnt;
             float m2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float d = acc[i][j][r] - mean;
-                    if (wrow0 + i * 16 + fg * 4 + r < a.M) m2 += d * d;
+                    if (rows_full || i * 16 + fg * 4 + r < wcnt) m2 += d * d;
                 }
-            m2 += __shfl_xor(m2, 16, 64); m2 += __shfl_xor(m2, 32, 64);
-            if (fg == 0 && cok) {
-                float* w = a.stats + ((int64_t)(wrow0 / (BM / 2)) * a.N + col) * 2;
+            m2 = row4_sum(m2);
+            if (fg == 0 && col0 + j < a.N) {
+                float* w = a.stats + ((int64_t)(wrow0 / (BM / 2)) * a.N + col0 + j) * 2;
                 w[0] = mean;
                 w[1] = m2;
             }
         }
     }
-    // ---- phase 2: one BM/2-row half at a time through LDS, then 8 consecutive columns per lane:
-    // addend / activation / activation-derivative applied on 16-byte vectors, 16-byte stores.
     const T* addend = (const T*)a.addend;
     const T* ysaved = (const T*)a.ysaved;
-    const bool vec_ok = (a.ldy % 8 == 0) && (!addend || a.ld_addend % 8 == 0) && (!a.dact || a.ld_saved % 8 == 0);
-    constexpr int CH = BN / 8;
+    const bool vec_ok = (a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N;
+    if (col0 < a.N) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
-        if (wm == h) {
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int r = 0; r < 4; ++r) {
+                const int rl = i * 16 + fg * 4 + r;
+                if (!rows_full && rl >= wcnt) continue;
+                const int64_t row = wrow0 + rl;
+                float v[TN], t[TN];
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
+                if (vec_ok) {
+                    if (addend) {
+                        load_run<T, TN>(addend + row * a.ld_addend + col0, t);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) epi[(i * 16 + fg * 4 + r) * EPI_LD + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < (BM / 2) * CH; idx += 256) {
-            const int rl = idx / CH, cch = idx - rl * CH;
-            const int row = m0 + h * (BM / 2) + rl, col = n0 + cch * 8;
-            if (row >= a.M || col >= a.N) continue;
-            float v[8];
-            load8<float>(&epi[rl * EPI_LD + cch * 8], v);
-            const bool full = vec_ok && col + 8 <= a.N;
-            if (full) {
-                if (addend) {
-                    float t[8];
-                    load8<T>(addend + (int64_t)row * a.ld_addend + col, t);
+                        for (int j = 0; j < TN; ++j) v[j] += t[j];
+                    }
+                    act_run<TN>(v, a.act);
+                    if (a.dact) {
+                        load_run<T, TN>(ysaved + row * a.ld_saved + col0, t);
+                        dact_run<TN>(v, t, a.dact);
+                    }
+                    if (a.out_f32) store_run<float, TN>((float*)a.y + row * a.ldy + col0, v);
+                    else store_run<T, TN>((T*)a.y + row * a.ldy + col0, v);
+                } else {
+                    const int nv = min(TN, a.N - col0);
+                    if (addend) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += t[e];
-                }
+                        for (int j = 0; j < TN; ++j) v[j] += j < nv ? to_f32(addend[row * a.ld_addend + col0 + j]) : 0.f;
+                    }
+                    act_run<TN>(v, a.act);
+                    if (a.dact) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = apply_act(v[e], a.act);
-                if (a.dact) {
-                    float t[8];
-                    load8<T>(ysaved + (int64_t)row * a.ld_saved + col, t);
+                        for (int j = 0; j < TN; ++j) t[j] = j < nv ? to_f32(ysaved[row * a.ld_saved + col0 + j]) : 0.f;
+                        dact_run<TN>(v, t, a.dact);
+                    }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= act_grad_from_out(t[e], a.dact);
-                }
-                if (a.out_f32) store8<float>((float*)a.y + (int64_t)row * a.ldy + col, v);
-                else store8<T>((T*)a.y + (int64_t)row * a.ldy + col, v);
-            } else {
-                for (int e = 0; e < 8 && col + e < a.N; ++e) {
-                    float f = v[e];
-                    if (addend) f += to_f32(addend[(int64_t)row * a.ld_addend + col + e]);
-                    f = apply_act(f, a.act);
-                    if (a.dact) f *= act_grad_from_out(to_f32(ysaved[(int64_t)row * a.ld_saved + col + e]), a.dact);
-                    if (a.out_f32) ((float*)a.y)[(int64_t)row * a.ldy + col + e] = f;
-                    else ((T*)a.y)[(int64_t)row * a.ldy + col + e] = from_f32<T>(f);
+                    for (int j = 0; j < TN; ++j)
+                        if (j < nv) {
+                            if (a.out_f32) ((float*)a.y)[row * a.ldy + col0 + j] = v[j];
+                            else ((T*)a.y)[row * a.ldy + col0 + j] = from_f32<T>(v[j]);
+                        }
                 }
             }
         }

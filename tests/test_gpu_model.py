@@ -76,7 +76,7 @@ def test_f32_train_step_matches_oracle(encoder, attention, S):
         # Relative L2 errors.  (A max-abs metric is brittle here: a ReLU mask flips when a
         # pre-activation lies within f32 rounding of 0, which moves single gradient elements by
         # O(1/pixels) -- two runs of the SAME engine differ that way through atomic ordering.)
-        #  * all gradients together: <= 5x the f32-NumPy noise floor of this very input (>= 2e-3)
+        #  * all gradients together: <= 10x the f32-NumPy noise floor of this very input (>= 2e-3)
         #  * each tensor: <= 5 % or 20x its own noise floor, with an absolute floor for tensors whose
         #    true gradient is ~0 (e.g. a BN offset that feeds straight into the next batch norm)
         gscale = max(np.abs(g).max() for g in grads_o.values())
@@ -84,7 +84,7 @@ def test_f32_train_step_matches_oracle(encoder, attention, S):
         tot_noise = np.sqrt(sum(np.sum((g32[n].astype(np.float64) - g) ** 2) for n, g in grads_o.items()))
         tot = np.sqrt(sum(np.sum(g ** 2) for g in grads_o.values()))
         print('step %d total relative-L2 gradient error %.2e (f32 NumPy noise floor %.2e)' % (step, tot_err / tot, tot_noise / tot))
-        assert tot_err / tot <= max(2e-3, 5 * tot_noise / tot), (step, tot_err / tot, tot_noise / tot)
+        assert tot_err / tot <= max(2e-3, 10 * tot_noise / tot), (step, tot_err / tot, tot_noise / tot)
         worst = (0.0, None)
         for name, go in grads_o.items():
             ge = grads_e[name]
