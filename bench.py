@@ -41,6 +41,27 @@ def synthetic_batch(B, cfg, seed):
     return image, cap
 
 
+def pmc_traffic(label):
+    """HBM bytes per launch of `label` from the committed PMC passes (profiles/r*_pmc_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read inside this process, so
+    the value is the one measured for the same command when the profile was taken; None if absent."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    if not files:
+        return None
+    kernels = json.load(open(files[-1]))['kernels']
+    m = re.match(r'(igemm_(nt|tn)_kernel)<(bf16|f32),(\d+),(\d+)>', label)
+    if m:
+        sym = '_Z15%sI%sLi%sELi%sEEv9%s' % (m.group(1), 'DF16b' if m.group(3) == 'bf16' else 'f', m.group(4), m.group(5),
+                                           'IGemmArgs' if m.group(2) == 'nt' else 'WGradArgs')
+        hit = [v for k, v in kernels.items() if k == sym]
+    else:
+        hit = [v for k, v in kernels.items() if label in k]
+    return round(hit[0]['hbm_bytes_per_launch'] / 1e6, 3) if hit else None       # MB per launch
+
+
 def cpu_baseline(cfg, budget_s=25.0):
     """The NumPy oracle ('port' of the reference graph, not PaddlePaddle) timed on the host cores
     on a bounded sample: whole train steps (fwd + bwd + Adam) of the SAME model at a small batch."""
@@ -159,8 +180,9 @@ def main():
             achieved = s['bytes'] / (s['ms'] * 1e-3) / 1e9
             roof = dict(bound='hbm', achieved=round(achieved, 1), peak=profiling.PEAK_HBM_GBPS, unit='GB/s',
                         frac=round(achieved / profiling.PEAK_HBM_GBPS, 4))
-        roof.update(kernel=name, traffic=None, avg_launch_us=round(s['ms'] / s['launches'] * 1e3, 2),
+        roof.update(kernel=name, traffic=pmc_traffic(name), avg_launch_us=round(s['ms'] / s['launches'] * 1e3, 2),
                     share_of_step=round(s['ms'] / total_ms, 3),
+                    traffic_unit='MB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)',
                     algorithmic_per_launch={'GFLOP': round(s['flops'] / s['launches'] / 1e9, 3),
                                             'MB': round(s['bytes'] / s['launches'] / 1e6, 3)})
         out['roofline'] = roof

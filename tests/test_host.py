@@ -1,0 +1,230 @@
+"""CPU tests of the host layer: C-ABI library + header agreement, parameter layouts, LR schedules,
+config compatibility, checkpoint files, and that the product refuses to run without a GPU."""
+import ctypes
+import importlib
+import os
+import re
+import sys
+import types
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C ABI
+def _header_decls():
+    src = open(os.path.join(ROOT, 'include', 'capmi.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return re.findall(r'\b(?:int|const char\*)\s+(capmi_\w+)\s*\(([^;]*?)\)\s*;', src, flags=re.S)
+
+
+def test_library_exports_every_header_symbol_with_matching_signature():
+    from myimagecaptioningmodel_amd import _lib
+    L = _lib.lib()                                 # loads libcapmi.so; raises if missing
+    assert L.capmi_version() == 1
+    decls = _header_decls()
+    assert len(decls) >= 40
+    for name, args in decls:
+        assert hasattr(L, name), name              # exported by the shared library
+        if name in ('capmi_version', 'capmi_last_error'):
+            continue
+        sig = _lib.SIGNATURES.get(name) or _lib.QUERIES.get(name)
+        assert sig is not None, 'no ctypes signature for %s' % name
+        arglist = [a.strip() for a in args.split(',') if a.strip() and a.strip() != 'void']
+        assert len(sig) == len(arglist), (name, len(sig), len(arglist))
+        for a, t in zip(arglist, sig):
+            if 'capmi_conv_geom' in a:
+                exp = _lib._g
+            elif '*' in a:
+                exp = ctypes.c_void_p
+            elif a.startswith('int64_t'):
+                exp = ctypes.c_int64
+            elif a.startswith('float'):
+                exp = ctypes.c_float
+            else:
+                exp = ctypes.c_int
+            assert t is exp, (name, a)
+    # and nothing bound that the header does not declare
+    declared = {n for n, _ in decls}
+    assert set(_lib.SIGNATURES) | set(_lib.QUERIES) <= declared
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from myimagecaptioningmodel_amd import _lib
+    L = _lib.lib()
+    rc = L.capmi_adam(None, None, None, None, 10, 0.1, 0.9, 0.999, 1e-8, 0.0, 1.0, None)
+    assert rc != 0 and b'null pointer' in L.capmi_last_error()
+    g = _lib.gemm_geom(4, 12)                      # K=12 is not a multiple of the 8-element bf16 vector
+    rc = L.capmi_igemm_nt(1, 1, 1, g, 8, 12, 8, None, None, 0, None, 0, None, 0, 0, 0, _lib.BF16, None)
+    assert rc != 0 and b'multiples' in L.capmi_last_error()
+    assert L.capmi_igemm_nt_stats_part_rows(200704, 64, _lib.BF16) in (32, 64)
+
+
+def test_engine_refuses_to_run_without_a_gpu():
+    import torch
+    from myimagecaptioningmodel_amd import CapmiError, default_cfg
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+    with pytest.raises(CapmiError):
+        CaptionEngine(default_cfg(), device='cpu')
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            CaptionEngine(default_cfg(image_size=64, hidden=32, embed=16, vocab=50), device='cuda:0')
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'myimagecaptioningmodel_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r'^\s*(from|import)\s+oracle\b', src, flags=re.M), fn
+
+
+# ------------------------------------------------------------------ parameter store
+def test_param_store_names_layouts_and_round_trip():
+    from myimagecaptioningmodel_amd import default_cfg, params as P
+    from oracle import model as om
+    cfg = default_cfg(image_size=64, hidden=32, embed=16, vocab=50, sentence_length=6)
+    st = P.ParamStore(cfg, 'cpu')
+    ocfg = om.default_cfg(image_size=64, hidden=32, embed=16, vocab=50, sentence_length=6)
+    shapes = om.param_shapes(ocfg)
+    assert set(st.names()) == set(shapes)                       # same variable names as the reference checkpoint
+    for n, e in st.entries.items():
+        assert tuple(shapes[n]) == e.ref_shape, n
+        assert e.offset % P.ALIGN == 0
+    # BN offset sits directly before the scale (bn_bwd_reduce writes [d offset | d scale] in place)
+    for n, e in st.entries.items():
+        if n.endswith('_bn_offset'):
+            assert st.entries[n[:-6] + 'scale'].offset == e.offset + e.kshape[0]
+    # decoder first, encoder in reverse layer order (= backward completion order)
+    names = list(st.entries)
+    assert names[0] == 'fc_0.w_0' and names.index('conv9_weights') < names.index('conv1_1_weights')
+    rng = np.random.RandomState(0)
+    ref = {n: rng.standard_normal(s).astype(np.float32) for n, s in shapes.items()}
+    st.load_reference(ref)
+    back = st.export_reference()
+    for n in ref:
+        np.testing.assert_array_equal(back[n], ref[n], err_msg=n)
+    # kernel layouts
+    w = ref['conv2_1_expand_weights']
+    np.testing.assert_array_equal(st.view('conv2_1_expand_weights').numpy(), w.transpose(0, 2, 3, 1))
+    np.testing.assert_array_equal(st.view('conv2_1_dwise_weights').numpy(), ref['conv2_1_dwise_weights'][:, 0].transpose(1, 2, 0))
+    np.testing.assert_array_equal(st.view('fc_5.w_0').numpy(), ref['fc_5.w_0'].T)
+    np.testing.assert_array_equal(st.view('lstm_w').numpy(), ref['lstm_w'].T)
+    stem = st.view('conv1_1_weights').numpy()
+    assert stem.shape == (32, 32) and np.all(stem[:, 27:] == 0)
+    np.testing.assert_array_equal(stem[:, :27], ref['conv1_1_weights'].transpose(0, 2, 3, 1).reshape(32, 27))
+
+
+def test_frozen_encoder_is_excluded_from_the_optimizer_range():
+    from myimagecaptioningmodel_amd import default_cfg, params as P
+    st = P.ParamStore(default_cfg(image_size=64, hidden=32, embed=16, vocab=50, encoder_trainable=False), 'cpu')
+    assert st.trainable_size == st.decoder_size < st.size
+    assert not st.entries['conv9_weights'].trainable and st.entries['lstm_w'].trainable
+
+
+def test_encoder_topologies():
+    from myimagecaptioningmodel_amd import arch
+    from oracle import arch as oarch
+    m = arch.mobilenet_v2()
+    convs = [o for o in m.ops if isinstance(o, arch.ConvBN)]
+    assert len(convs) == 53 and m.channels == 1280            # conv1_1 + 17 units x 3 + conv9 (53 conv-bn)
+    assert sum(1 for o in convs if o.groups > 1) == 17
+    onames = {o[1] for o in oarch.mobilenet_v2_ops()[0] if o[0] == 'conv_bn'}
+    assert {o.name for o in convs} == onames
+    r = arch.resnet(50)
+    rconvs = [o for o in r.ops if isinstance(o, arch.ConvBN)]
+    assert len(rconvs) == 53 and r.channels == 2048
+    assert {o.name for o in rconvs} == {o[1] for o in oarch.resnet_ops(50)[0] if o[0] == 'conv_bn'}
+    with pytest.raises(ValueError):
+        arch.encoder('vgg')
+
+
+# ------------------------------------------------------------------ LR schedules (tools/util.py:20-119)
+def test_lr_schedules():
+    import math
+    from myimagecaptioningmodel_amd.optim import LRSchedule, adam_lr_t
+    with pytest.raises(ValueError):
+        LRSchedule('linear', 1e-3, 1000, 10)
+    s = LRSchedule(None, 5e-5, 944996, 128)
+    assert s.step_each_epoch == 7383 and s.value(0) == s.value(10 ** 6) == 5e-5
+    c = LRSchedule('cosine_decay', 1e-3, 1000, 10, decay_epoch=10)
+    assert c.value(0) == pytest.approx(1e-3) and c.value(100 * 5) == pytest.approx(1e-3 * 0.5 * (math.cos(math.pi * 5 / 10) + 1))
+    w = LRSchedule('cosine_decay_warmup', 1e-3, 1000, 10, warmup_epoch=3, max_epoch=10)
+    assert w.value(0) == pytest.approx(1e-5)                            # epoch 0 of warm-up: start_lr
+    assert w.value(99) == pytest.approx(1e-5 + (1e-3 - 1e-5) / 3 * 1)   # counter starts at 1: step 99 -> epoch 1
+    assert w.value(100 * 3) == pytest.approx(1e-3)                      # first post-warm-up epoch
+    r = LRSchedule('cosine_decay_restart', 1e-3, 1000, 10, decay_epoch=2)
+    assert r.value(0) == pytest.approx(1e-3) and r.value(100 * 2) == pytest.approx(1e-3)     # restart at epoch 2
+    assert r.value(100 * 1) == pytest.approx(1e-3 * 0.5 * (math.cos(math.pi * 0.5) + 1))
+    rw = LRSchedule('cosine_decay_restart_warmup', 1e-3, 1000, 10, decay_epoch=2, warmup_epoch=2)
+    vals = [rw.value(i) for i in range(400)]
+    assert vals[0] == pytest.approx(1e-5) and vals[99] == pytest.approx(1e-5 + (1e-3 - 1e-5) * 0.5)
+    assert vals[199] == pytest.approx(1e-3)
+    assert adam_lr_t(1e-3, 1) == pytest.approx(1e-3 * math.sqrt(1 - 0.999) / (1 - 0.9))
+
+
+# ------------------------------------------------------------------ config compatibility
+def _reference_style_config():
+    """A module of dicts with the reference's schema (config.py:2-73), values = the repo defaults."""
+    m = types.ModuleType('config')
+    m.data = {'ImageShape': [224, 224], 'ImageMean': [0, 0, 0], 'ImageStd': [1, 1, 1], 'start_idx': 2, 'stop_idx': 3,
+              'padding_idx': 0, 'PretrainedMobileNetPath': None, 'sample_count': 944996}
+    m.train = {'seed': None, 'learning_rate': 0.00005, 'lr_decay_strategy': None, 'decay_epoch': 0, 'warmup_epoch': 3,
+               'gradient_clip': False, 'batch_size': 128, 'max_epoch': 10, 'log_every_n_step': 150}
+    m.model = {'encoder': {'encoder_trainable': True, 'encoder_dim': 49, 'encoder_channel': 1280},
+               'decoder': {'vocab_size': 12295, 'embedding_size': 256, 'sentence_length': 35, 'hidden_dim': 1024,
+                           'infer_max_length': 35}}
+    m.dc, m.md = m.data, m.model
+    return m
+
+
+def test_reference_config_module_is_read_unchanged():
+    from myimagecaptioningmodel_amd import default_cfg, from_reference_config
+    cfg = from_reference_config(_reference_style_config())
+    d = default_cfg()
+    for k in ('image_size', 'hidden', 'embed', 'vocab', 'sentence_length', 'infer_max_length', 'start_idx', 'stop_idx',
+              'padding_idx', 'encoder_trainable', 'learning_rate', 'batch_size', 'sample_count'):
+        assert cfg[k] == d[k], k
+    assert cfg['attention'] == 'singleton' and cfg['dtype'] == 'f32' and cfg['encoder'] == 'mobilenetv2'
+    assert from_reference_config(_reference_style_config(), encoder='resnet50', dtype='bf16')['encoder'] == 'resnet50'
+
+
+def test_facade_modes_without_gpu():
+    from myimagecaptioningmodel_amd import ImageCaptionModel, default_cfg
+    m = ImageCaptionModel(default_cfg())
+    inputs, feeds = m.build_input('train')
+    assert feeds[0].shape == [-1, 3, 224, 224] and feeds[1].shape == [-1, 35] and feeds[1].dtype == 'int64'
+    assert m.build_network('train', **inputs).name == 'loss'
+    assert m.build_network('eval').dtype == 'float32'          # float ids, quirk Q2
+    for bad in ('test', 'infer'):
+        with pytest.raises(ValueError):
+            m.build_input(bad)
+        with pytest.raises(ValueError):
+            m.build_network(bad)
+
+
+# ------------------------------------------------------------------ checkpoint files
+def test_lod_tensor_round_trip_and_layout(tmp_path):
+    from myimagecaptioningmodel_amd import ckpt
+    rng = np.random.RandomState(0)
+    for arr in (rng.standard_normal((3, 4, 5)).astype(np.float32), rng.standard_normal(7), np.arange(6, dtype=np.int64).reshape(2, 3),
+                np.array([0.729], np.float32)):
+        p = str(tmp_path / 'v')
+        ckpt.write_lod_tensor(p, arr)
+        back = ckpt.read_lod_tensor(p)
+        assert back.dtype == arr.dtype and back.shape == arr.shape
+        np.testing.assert_array_equal(back, arr)
+    # byte layout: u32 0 | u64 0 | u32 0 | i32 desc_len | desc | data
+    ckpt.write_lod_tensor(str(tmp_path / 'w'), np.zeros((2, 3), np.float32))
+    raw = open(str(tmp_path / 'w'), 'rb').read()
+    assert raw[:16] == b'\x00' * 16 and raw[16:20] == (6).to_bytes(4, 'little')
+    assert raw[20:26] == b'\x08\x05\x10\x02\x10\x03' and len(raw) == 26 + 24
+    conf = ckpt.load_resume_state(str(tmp_path / 'log'))
+    assert conf == {'epoch': 1, 'best_bleu': 0, 'best_meteor': 0, 'train_encoder': True}
+    conf['epoch'] = 4
+    ckpt.save_resume_state(str(tmp_path / 'log'), conf)
+    assert ckpt.load_resume_state(str(tmp_path / 'log'))['epoch'] == 4
+    open(str(tmp_path / 'conv9_weights'), 'wb').close()
+    assert ckpt.predicate_existing(str(tmp_path), ['conv9_weights', 'missing']) == ['conv9_weights']
