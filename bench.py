@@ -54,9 +54,8 @@ def pmc_traffic(label):
     kernels = json.load(open(files[-1]))['kernels']
     m = re.match(r'(igemm_(nt|tn)_kernel)<(bf16|f32),(\d+),(\d+)>', label)
     if m:
-        sym = '_Z15%sI%sLi%sELi%sEEv9%s' % (m.group(1), 'DF16b' if m.group(3) == 'bf16' else 'f', m.group(4), m.group(5),
-                                           'IGemmArgs' if m.group(2) == 'nt' else 'WGradArgs')
-        hit = [v for k, v in kernels.items() if k == sym]
+        pre = '_Z15%sI%sLi%sELi%sE' % (m.group(1), 'DF16b' if m.group(3) == 'bf16' else 'f', m.group(4), m.group(5))
+        hit = [v for k, v in kernels.items() if k.startswith(pre)]
     else:
         hit = [v for k, v in kernels.items() if label in k]
     return round(hit[0]['hbm_bytes_per_launch'] / 1e6, 3) if hit else None       # MB per launch

@@ -47,13 +47,13 @@ typedef struct {
  * 104,107,115,196,198), the lstm_unit gate fc (:87-88) and the tied vocabulary projection
  * matmul(transpose_y=True) (:25), forward and data-gradient.
  * Epilogue, in order: (+ bias[n]) (+ addend[m][n]) -> optional fused batch-norm statistics: for
- * every block of capmi_igemm_nt_stats_part_rows(M,N,dtype) consecutive rows and every column the
+ * every block of capmi_igemm_nt_stats_part_rows(M,N,K,dtype) consecutive rows and every column the
  * exact (mean, sum (v-mean)^2) of the f32 accumulators, stored to stats[part][N][2] (plain
  * stores: deterministic, cancellation-free; merged by capmi_bn_finalize)
  * -> act -> (* act'(ysaved[m][n]) when dact != NONE: ysaved holds the forward OUTPUT of that
  * activation) -> store as `dtype`, or f32 when out_f32.
  * Requires Cin % (16/sizeof(elem)) == 0 and ldx, ldw likewise; N, M arbitrary. */
-int capmi_igemm_nt_stats_part_rows(int M, int N, int dtype);
+int capmi_igemm_nt_stats_part_rows(int M, int N, int K, int dtype);
 int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom* g,
                    int N, int ldw, int ldy,
                    const float* bias, const void* addend, int ld_addend,
@@ -203,6 +203,10 @@ int capmi_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr
  * (taps flipped; columns N..ldt zero; ldt > N only for 1x1 weights). */
 int capmi_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
 int capmi_weight_dgrad_form(const float* w, void* wt, int N, int kh, int kw, int C, int ldt, int dtype, void* stream);
+/* The same for every GEMM weight of a model in one launch.  jobs: device array of
+ *   struct { int64 src_off, dst_off; int32 N, kh, kw, C, ldt, first; }   (40 bytes, one per 65536-
+ * element slice of one weight's output; offsets in elements into `flat` (f32) / `shadow` (`dtype`)). */
+int capmi_weight_dgrad_form_batched(const float* flat, void* shadow, const void* jobs, int njobs, int dtype, void* stream);
 int capmi_fill_f32(float* p, float value, int64_t n, void* stream);
 
 #ifdef __cplusplus

@@ -66,6 +66,7 @@ SIGNATURES = {
     'capmi_adam': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
     'capmi_cast': [_p, _p, _l, _i, _p],
     'capmi_weight_dgrad_form': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_weight_dgrad_form_batched': [_p, _p, _p, _i, _i, _p],
     'capmi_fill_f32': [_p, _f, _l, _p],
 }
 
@@ -76,7 +77,7 @@ class CapmiError(RuntimeError):
 
 # queries without a stream argument: name -> argument ctypes (return the part size, > 0)
 QUERIES = {
-    'capmi_igemm_nt_stats_part_rows': [_i, _i, _i],
+    'capmi_igemm_nt_stats_part_rows': [_i, _i, _i, _i],
     'capmi_bn_stats_part_rows': [_i, _i, _i],
     'capmi_bn_bwd_ws_floats': [_i, _i, _i],
 }

@@ -22,7 +22,20 @@ struct IGemmArgs {
     int ldw, ldy, ld_addend, ld_saved;
     capmi_conv_geom g;
     int act, dact, out_f32;
+#ifdef CAPMI_STAMPS
+    unsigned long long* stamps;      // diagnostic build only: [workgroup][8] s_memtime stamps
+#endif
 };
+#ifdef CAPMI_STAMPS
+static unsigned long long* g_stamp_buffer = nullptr;
+extern "C" void capmi_debug_set_stamp_buffer(void* p) { g_stamp_buffer = (unsigned long long*)p; }
+#define STAMP(slot)                                                                                   \
+    do {                                                                                              \
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------ MFMA wrappers
 template <typename T> struct Frag;
@@ -147,7 +160,16 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 
 // TN consecutive output values of one row -> one vector store (bf16: 4/8 bytes, f32: 8/16 bytes)
 template <typename O, int TN> __device__ __forceinline__ void store_run(O* p, const float (&v)[TN]) {
-    if constexpr (sizeof(O) == 2) {
+    if constexpr (TN == 8) {
+        float lo[4] = {v[0], v[1], v[2], v[3]}, hi[4] = {v[4], v[5], v[6], v[7]};
+        if constexpr (sizeof(O) == 2) {
+            bf16x8 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3], (bf16)v[4], (bf16)v[5], (bf16)v[6], (bf16)v[7]};
+            *reinterpret_cast<bf16x8*>(p) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(p) = f32x4{lo[0], lo[1], lo[2], lo[3]};
+            *reinterpret_cast<f32x4*>(p + 4) = f32x4{hi[0], hi[1], hi[2], hi[3]};
+        }
+    } else if constexpr (sizeof(O) == 2) {
         if constexpr (TN == 4) {
             bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
             *reinterpret_cast<bf16x4*>(p) = o;
@@ -165,7 +187,17 @@ template <typename O, int TN> __device__ __forceinline__ void store_run(O* p, co
     }
 }
 template <typename O, int TN> __device__ __forceinline__ void load_run(const O* p, float (&v)[TN]) {
-    if constexpr (sizeof(O) == 2) {
+    if constexpr (TN == 8) {
+        if constexpr (sizeof(O) == 2) {
+            bf16x8 o = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)o[e];
+        } else {
+            f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+        }
+    } else if constexpr (sizeof(O) == 2) {
         if constexpr (TN == 4) {
             bf16x4 o = *reinterpret_cast<const bf16x4*>(p);
 #pragma unroll
@@ -236,9 +268,9 @@ template <int TN> __device__ __forceinline__ void dact_run(float (&v)[TN], const
 // fragment reads keep their conflict-free addresses).  Each lane then owns TN CONSECUTIVE output
 // columns of every row it holds: the epilogue stores straight from registers -- a wave instruction
 // writes 4 rows x (16 lanes x TN values) = whole 128-byte lines (bf16, TN = 4), no LDS round trip.
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int WMW>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
-    // BK = 64 with ONE LDS stage + one stage in registers: the next tile's 16-byte loads (8 per
+    // WMW x (4/WMW) waves.  BK = 64 with ONE LDS stage + one stage in registers: the next tile's 16-byte loads (8 per
     // thread for a 128x128 tile) are in flight during the whole compute phase.  The small-K convs
     // are bound by memory concurrency (bytes in flight per CU), not by MFMA or LDS.
     constexpr int BK = 64;
@@ -247,15 +279,18 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
     constexpr int LD = BK + VEC;           // padded LDS row, elements (16-byte aligned rows)
     constexpr int RSTEP = 256 / CPR;
     constexpr int ACH = BM / RSTEP, BCH = BN / RSTEP;
-    constexpr int TM = BM / 32, TN = BN / 32;
-    constexpr int WN = BN / 2;             // columns per wave
+    constexpr int WNW = 4 / WMW;           // waves along N
+    constexpr int RW = BM / WMW;           // rows per wave
+    constexpr int WN = BN / WNW;           // columns per wave
+    constexpr int TM = RW / 16, TN = WN / 16;
+    static_assert(TN == 2 || TN == 4 || TN == 8, "lane owns 2, 4 or 8 consecutive columns");
     __shared__ __attribute__((aligned(16))) T As[BM * LD];
     __shared__ __attribute__((aligned(16))) T Bs[BN * LD];
 
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ W = (const T*)a.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave % WNW;
     const int tiles_n = (a.N + BN - 1) / BN;
     const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     const int m0 = (tile / tiles_n) * BM;
@@ -302,17 +337,20 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
 
     const int nkt = (a.K + BK - 1) / BK;
     const int fr = lane & 15, fg = lane >> 4;
+    STAMP(0);
     load_tile();
+    STAMP(1);
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt) __syncthreads();                 // every wave is done reading the previous tile
         store_tile();
+        if (kt == 0) STAMP(2);
         __syncthreads();
         if (kt + 1 < nkt) load_tile();           // in flight during the MFMAs below
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             Frag<T> af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i].load(&As[(wm * (BM / 2) + i * 16 + fr) * LD + ks * 32 + fg * 8]);
+            for (int i = 0; i < TM; ++i) af[i].load(&As[(wm * RW + i * 16 + fr) * LD + ks * 32 + fg * 8]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j].load(&Bs[(wn * WN + j * 16 + fr) * LD + ks * 32 + fg * 8]);
 #pragma unroll
@@ -322,11 +360,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
         }
     }
 
+    STAMP(3);
     // ---- epilogue (registers only).  acc[i][j][r] = output (row wrow0 + 16i + 4fg + r, column col0 + j).
-    const int wrow0 = m0 + wm * (BM / 2);                      // first row of this wave's sub-tile
-    const int wcnt = min(BM / 2, a.M - wrow0);                 // valid rows in it (<= 0: none)
+    const int wrow0 = m0 + wm * RW;                            // first row of this wave's sub-tile
+    const int wcnt = min(RW, a.M - wrow0);                     // valid rows in it (<= 0: none)
     const int col0 = n0 + wn * WN + TN * fr;                   // this lane's TN consecutive columns
-    const bool rows_full = wcnt == BM / 2;
+    const bool rows_full = wcnt == RW;
     if (a.bias) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -338,7 +377,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
         }
     }
     if (a.stats && wcnt > 0) {
-        // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) of this wave's BM/2-row block
+        // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) of this wave's RW-row block
         // per column, from the f32 accumulators; plain stores, one producer per (part, column):
         // deterministic and cancellation-free (merged by bn_finalize, bn_ops.hip).
 #pragma unroll
@@ -360,12 +399,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
                 }
             m2 = row4_sum(m2);
             if (fg == 0 && col0 + j < a.N) {
-                float* w = a.stats + ((int64_t)(wrow0 / (BM / 2)) * a.N + col0 + j) * 2;
+                float* w = a.stats + ((int64_t)(wrow0 / RW) * a.N + col0 + j) * 2;
                 w[0] = mean;
                 w[1] = m2;
             }
         }
     }
+    STAMP(4);
     const T* addend = (const T*)a.addend;
     const T* ysaved = (const T*)a.ysaved;
     const bool vec_ok = (a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N;
@@ -415,33 +455,167 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
             }
         }
     }
+    STAMP(5);
+#ifdef CAPMI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(6);
+#endif
 }
 
-// tile selection shared by the launcher and the statistics-workspace query
-static void nt_tile(int M, int N, int dtype, int* bm, int* bn) {
-    const bool wide = N > 64;
-    const bool tall = (int64_t)cdiv(M, 128) * cdiv(N, wide ? 128 : 64) >= 256;
-    if (dtype == CAPMI_BF16) {
-        *bm = tall ? 128 : 64;
-        *bn = wide ? 128 : 64;
-    } else {                      // f32 tiles are twice the bytes: stay under 64 KiB of static LDS
-        *bm = wide ? 64 : (tall ? 128 : 64);
-        *bn = wide ? 128 : 64;
+// ------------------------------------------------------------------ skinny NT kernel (M <= 64)
+// The decoder's recurrent GEMMs ([B,H]x[H,4H] forward, [B,4H]x[4H,H] in BPTT; B = 64) are chains of
+// tiny dependent launches: with the tiled kernel they run on 4-16 workgroups and pay one memory
+// latency per k-tile.  Here a workgroup owns a 64x32 output tile, its 4 waves split K four ways,
+// every wave streams its fragments straight from global memory (L2-resident) into MFMA operand
+// layout -- no LDS, no barrier in the main loop, loads several k-steps ahead -- and the four partial
+// tiles meet in LDS once.  Plain row-major A only (no im2col).
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_nt_skinny_kernel(IGemmArgs a) {
+    constexpr int TM = 4, TN = 2;                      // 64 x 32 tile per workgroup
+    __shared__ __attribute__((aligned(16))) float red[4][TM * TN][64][4];
+    const T* __restrict__ X = (const T*)a.x;
+    const T* __restrict__ W = (const T*)a.w;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 32;
+    const int kper = a.K / 4;                          // launcher guarantees K % 128 == 0
+    const int kbeg = wave * kper;
+    const int ldx = a.g.ldx;
+
+    const T* arow[TM];
+    bool aok[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = i * 16 + fr;
+        aok[i] = m < a.M;
+        arow[i] = X + (int64_t)(aok[i] ? m : 0) * ldx + kbeg + fg * 8;
+    }
+    const T* brow[TN];
+    bool bok[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + TN * fr + j;                // lane owns TN consecutive columns (see igemm_nt_kernel)
+        bok[j] = n < a.N;
+        brow[j] = W + (int64_t)(bok[j] ? n : 0) * a.ldw + kbeg + fg * 8;
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 4
+    for (int k = 0; k < kper; k += 32) {
+        Frag<T> af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            af[i].load(arow[i] + k);
+            if (!aok[i]) af[i] = Frag<T>{};
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            bf[j].load(brow[j] + k);
+            if (!bok[j]) bf[j] = Frag<T>{};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma16(acc[i][j], af[i], bf[j]);
+    }
+    // cross-wave reduction: wave w finishes rows 16w..16w+15 (tiles (w, 0..TN-1))
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(&red[wave][i * TN + j][lane][0]) = acc[i][j];
+    __syncthreads();
+    float v[4][TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(&red[0][wave * TN + j][lane][0]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(&red[w][wave * TN + j][lane][0]);
+            s += t;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r][j] = s[r];
+    }
+    const int col0 = n0 + TN * fr;
+    if (col0 >= a.N) return;
+    const T* addend = (const T*)a.addend;
+    const T* ysaved = (const T*)a.ysaved;
+    const bool vec_ok = (a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N;
+    const int nv = min(TN, a.N - col0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = wave * 16 + fg * 4 + r;
+        if (row >= a.M) continue;
+        float o[TN], t[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) o[j] = v[r][j] + ((a.bias && j < nv) ? a.bias[col0 + j] : 0.f);
+        if (addend) {
+            if (vec_ok) load_run<T, TN>(addend + row * a.ld_addend + col0, t);
+            else
+#pragma unroll
+                for (int j = 0; j < TN; ++j) t[j] = j < nv ? to_f32(addend[row * a.ld_addend + col0 + j]) : 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) o[j] += t[j];
+        }
+        act_run<TN>(o, a.act);
+        if (a.dact) {
+            if (vec_ok) load_run<T, TN>(ysaved + row * a.ld_saved + col0, t);
+            else
+#pragma unroll
+                for (int j = 0; j < TN; ++j) t[j] = j < nv ? to_f32(ysaved[row * a.ld_saved + col0 + j]) : 0.f;
+            dact_run<TN>(o, t, a.dact);
+        }
+        if (vec_ok) {
+            if (a.out_f32) store_run<float, TN>((float*)a.y + row * a.ldy + col0, o);
+            else store_run<T, TN>((T*)a.y + row * a.ldy + col0, o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (j < nv) {
+                    if (a.out_f32) ((float*)a.y)[row * a.ldy + col0 + j] = o[j];
+                    else ((T*)a.y)[row * a.ldy + col0 + j] = from_f32<T>(o[j]);
+                }
+        }
     }
 }
 
-extern "C" int capmi_igemm_nt_stats_part_rows(int M, int N, int dtype) {
-    int bm, bn;
-    nt_tile(M, N, dtype, &bm, &bn);
-    return bm / 2;
+// Tile / wave-grid selection shared by the launcher and the statistics-workspace query.
+//   bf16, N > 64 : 4x1 waves, each lane owns 8 consecutive columns (16-byte stores);
+//                  128x128 (2 workgroups/CU) when the reduction is deep (K >= 512) and the grid is
+//                  large, else 64x128 (32 accumulator registers -> 4 workgroups/CU): the small-K
+//                  convs are bound by memory concurrency, not by MFMA
+//   bf16, N <= 64: 128x64 / 64x64, 4x1 waves (8-byte stores)
+//   f32          : 2x2 waves, tiles sized for 64 KiB of static LDS
+struct NtCfg { int bm, bn, wmw; };
+static NtCfg nt_cfg(int M, int N, int K, int dtype) {
+    const bool wide = N > 64;
+    if (dtype == CAPMI_BF16) {
+        if (wide) {
+            const bool big = K >= 512 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 512;
+            return NtCfg{big ? 128 : 64, 128, 4};
+        }
+        const bool tall = cdiv(M, 128) >= 512;
+        return NtCfg{tall ? 128 : 64, 64, 4};
+    }
+    const bool tall = (int64_t)cdiv(M, 128) * cdiv(N, 64) >= 256;
+    return wide ? NtCfg{64, 128, 2} : NtCfg{tall ? 128 : 64, 64, 2};
 }
 
-template <typename T, int BM, int BN>
+extern "C" int capmi_igemm_nt_stats_part_rows(int M, int N, int K, int dtype) {
+    NtCfg c = nt_cfg(M, N, K, dtype);
+    return c.bm / c.wmw;
+}
+
+template <typename T, int BM, int BN, int WMW>
 static int launch_nt(const IGemmArgs& a, hipStream_t st) {
     int64_t tiles = (int64_t)cdiv(a.M, BM) * cdiv(a.N, BN);
     if (tiles <= 0) return 0;
     CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
-    hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WMW>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     CAPMI_LAUNCH_CHECK("capmi_igemm_nt");
     return 0;
 }
@@ -463,19 +637,29 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldw = ldw; a.ldy = ldy; a.ld_addend = ld_addend; a.ld_saved = ld_saved;
     a.g = *g; a.act = act; a.dact = dact; a.out_f32 = out_f32;
+#ifdef CAPMI_STAMPS
+    a.stamps = g_stamp_buffer;
+#endif
     CAPMI_CHECK(ldw >= a.K, "capmi_igemm_nt: ldw=%d < K=%d", ldw, a.K);
     hipStream_t st = (hipStream_t)stream;
-    int bm, bn;
-    nt_tile(a.M, N, dtype, &bm, &bn);
+    const bool plain = g->kh == 1 && g->kw == 1 && g->sd == 1 && g->up == 1 && g->pad == 0 && g->Hi == 1 && g->Wi == 1 && g->Ho == 1 && g->Wo == 1;
+    if (plain && !stats && a.M <= 64 && a.K % 128 == 0 && a.K >= 256 && (dtype == CAPMI_BF16 || dtype == CAPMI_F32)) {
+        // decoder recurrence and other M <= 64 products: skinny kernel (64x32 tiles, K split over waves)
+        if (dtype == CAPMI_BF16) hipLaunchKernelGGL(igemm_nt_skinny_kernel<bf16>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(igemm_nt_skinny_kernel<float>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);
+        CAPMI_LAUNCH_CHECK("capmi_igemm_nt(skinny)");
+        return 0;
+    }
+    const NtCfg c = nt_cfg(a.M, N, a.K, dtype);
     if (dtype == CAPMI_BF16) {
-        if (bm == 128 && bn == 128) return launch_nt<bf16, 128, 128>(a, st);
-        if (bm == 64 && bn == 128) return launch_nt<bf16, 64, 128>(a, st);
-        if (bm == 128 && bn == 64) return launch_nt<bf16, 128, 64>(a, st);
-        return launch_nt<bf16, 64, 64>(a, st);
+        if (c.bm == 128 && c.bn == 128) return launch_nt<bf16, 128, 128, 4>(a, st);
+        if (c.bm == 64 && c.bn == 128) return launch_nt<bf16, 64, 128, 4>(a, st);
+        if (c.bm == 128 && c.bn == 64) return launch_nt<bf16, 128, 64, 4>(a, st);
+        return launch_nt<bf16, 64, 64, 4>(a, st);
     } else if (dtype == CAPMI_F32) {
-        if (bm == 64 && bn == 128) return launch_nt<float, 64, 128>(a, st);
-        if (bm == 128 && bn == 64) return launch_nt<float, 128, 64>(a, st);
-        return launch_nt<float, 64, 64>(a, st);
+        if (c.bm == 64 && c.bn == 128) return launch_nt<float, 64, 128, 2>(a, st);
+        if (c.bm == 128 && c.bn == 64) return launch_nt<float, 128, 64, 2>(a, st);
+        return launch_nt<float, 64, 64, 2>(a, st);
     }
     capmi_set_error("capmi_igemm_nt: bad dtype %d", dtype);
     return 1;
@@ -614,11 +798,16 @@ template <typename T, int BNO, int BKO>
 static int launch_tn(WGradArgs& a, hipStream_t st) {
     int tiles = cdiv(a.N, BNO) * cdiv(a.K, BKO);
     if (tiles <= 0 || a.M <= 0) return 0;
-    // Splits over the reduction (pixel) axis: enough workgroups to fill 256 CUs, but each split
-    // at least 1024 rows deep -- every split adds its whole tile with f32 atomics, which the chip
-    // retires at only ~1.3 TB/s, so a shallow split costs more in atomics than it gains in occupancy.
-    int want = cdiv(512, tiles);
-    int max_splits = cdiv(a.M, 1024);
+    // Splits over the reduction (pixel) axis.  Every split adds its whole output tile with f32
+    // atomics, which the chip retires at only ~1.3 TB/s: cap the total atomic traffic
+    // (tiles x splits x tile bytes) at ~24 MB (~20 us) and keep every split >= 8 steps (256 rows)
+    // deep; within that, enough workgroups for ~3 per CU.
+    const long long out_elems = (long long)cdiv(a.N, BNO) * BNO * cdiv(a.K, BKO) * BKO;
+    long long by_atomics = (6ll << 20) / (out_elems > 0 ? out_elems : 1);
+    if (by_atomics < 1) by_atomics = 1;
+    int want = cdiv(768, tiles);
+    int max_splits = cdiv(a.M, 256);
+    if (max_splits > by_atomics) max_splits = (int)by_atomics;
     int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     int per = cdiv(a.M, splits);
     per = (per + 31) / 32 * 32;

@@ -77,6 +77,42 @@ extern "C" int capmi_weight_dgrad_form(const float* w, void* wt, int N, int kh, 
     return 0;
 }
 
+// All data-gradient weight forms of a model in ONE launch: a job table in device memory, one job per
+// (weight, 64K-element slice); blocks pick their job by index.
+struct DgradJob {
+    long long src_off, dst_off;     // element offsets into the f32 master / the shadow buffer
+    int N, kh, kw, C, ldt;
+    int first;                      // first output element of this slice
+};
+template <typename T>
+__global__ __launch_bounds__(256) void dgrad_form_batched_kernel(const float* __restrict__ flat, T* shadow, const DgradJob* __restrict__ jobs) {
+    const DgradJob j = jobs[blockIdx.x];
+    const long long total = (long long)j.C * j.kh * j.kw * j.ldt;
+    const float* w = flat + j.src_off;
+    T* wt = shadow + j.dst_off;
+    for (int e = threadIdx.x; e < 65536; e += 256) {
+        long long i = (long long)j.first + e;
+        if (i >= total) break;
+        int n = (int)(i % j.ldt);
+        long long rest = i / j.ldt;
+        int q = (int)(rest % j.kw);
+        int r = (int)((rest / j.kw) % j.kh);
+        int c = (int)(rest / ((long long)j.kw * j.kh));
+        float f = 0.f;
+        if (n < j.N) f = w[(((long long)n * j.kh + (j.kh - 1 - r)) * j.kw + (j.kw - 1 - q)) * j.C + c];
+        wt[i] = from_f32<T>(f);
+    }
+}
+extern "C" int capmi_weight_dgrad_form_batched(const float* flat, void* shadow, const void* jobs, int njobs, int dtype, void* stream) {
+    CAPMI_CHECK(flat && shadow && jobs, "capmi_weight_dgrad_form_batched: null pointer");
+    if (njobs <= 0) return 0;
+    CAPMI_DISPATCH(dtype, "capmi_weight_dgrad_form_batched", {
+        hipLaunchKernelGGL(dgrad_form_batched_kernel<T>, dim3(njobs), dim3(256), 0, (hipStream_t)stream, flat, (T*)shadow, (const DgradJob*)jobs);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_weight_dgrad_form_batched");
+    return 0;
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* p, float value, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = value;
 }

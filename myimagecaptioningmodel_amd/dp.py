@@ -70,7 +70,12 @@ def allreduce_flat(flat, buckets, group=None, async_op=False):
 
 
 class OverlappedTrainer:
-    """Train step with gradient all-reduce overlapped with backward (one rank)."""
+    """Train step with the gradient all-reduce overlapped with backward (one instance per rank).
+
+    Backward is cut where a bucket of the flat gradient buffer becomes final (after the decoder,
+    then after encoder layers from last to first); each segment is its own hipGraph.  After a
+    segment is enqueued, an event is recorded on the compute stream and the bucket's all-reduce is
+    issued on a side stream behind that event; Adam waits for the side stream."""
 
     def __init__(self, engine, bucket_bytes=32 << 20):
         self.eng = engine
@@ -79,28 +84,31 @@ class OverlappedTrainer:
         self._progs = {}
 
     def _prepare(self, B):
+        from ._lib import Plan
         eng = self.eng
         prog = eng._train.get(B)
         if prog is None:
             prog = eng._train[B] = eng._compile_train(B)
-        st = eng.store
-        # segment boundaries: after the decoder, then after each encoder op (its params are final)
-        cut_calls, cut_offsets = [prog['n_dec']], [st.decoder_size]
+        st, bwd = eng.store, prog['bwd']
+        # (plan index, flat offset) pairs at which everything below the offset is final
+        cuts = [(prog['n_dec'], st.decoder_size)]
         for call_idx, opname in prog['marks']:
-            e = st.entries[opname + '_bn_scale']
-            cut_calls.append(call_idx)
-            cut_offsets.append(e.offset + (int(e.kshape[0]) + 7) // 8 * 8)
-        buckets = GradBuckets(st.trainable_size, cut_offsets, self.bucket_bytes)
-        # map each bucket end to the call index at which it is complete
+            e = st.entries[opname + '_bn_scale']                 # last entry of the op's group
+            cuts.append((call_idx, e.offset + (int(e.kshape[0]) + 7) // 8 * 8))
+        total = st.trainable_size
+        cuts = [(ci, off) for ci, off in cuts if off <= total]
+        assert all(a[1] <= b[1] and a[0] <= b[0] for a, b in zip(cuts, cuts[1:])), 'gradient order != backward order'
+        buckets = GradBuckets(total, [off for _, off in cuts], self.bucket_bytes)
+        index_of = {off: ci for ci, off in cuts}
         segs, start = [], 0
         for (b, e) in buckets:
-            idx = max(ci for ci, off in zip(cut_calls, cut_offsets) if off <= e) if e < st.trainable_size else len(prog['bwd'])
-            if e == st.trainable_size:
-                idx = len(prog['bwd'])
-            sub = _lib_plan_slice(prog['bwd'], start, idx)
-            segs.append((sub, (b, e)))
-            start = idx
-        return dict(prog=prog, segs=segs, graphs=[None] * (len(segs) + 1))
+            stop = len(bwd) if e == total else index_of[e]
+            sub = Plan()
+            sub.calls, sub._keep = bwd.calls[start:stop], bwd._keep[start:stop]
+            segs.append((sub, (b, e), {}))
+            start = stop
+        assert start == len(bwd)
+        return dict(prog=prog, segs=segs, fwd_graph={})
 
     def train_step(self, image, caption):
         eng = self.eng
@@ -115,32 +123,16 @@ class OverlappedTrainer:
             eng.refresh_shadows()
         eng._feed_train(prog, image, caption)
         cur = torch.cuda.current_stream(eng.device)
-        holder = {}
-        eng._run_captured(holder_graph(P, 0), 'g', [prog['fwd']])
-        st = eng.store
-        for i, (sub, (b, e)) in enumerate(P['segs']):
-            eng._run_captured(holder_graph(P, i + 1), 'g', [sub])
+        eng._run_captured(P['fwd_graph'], 'g', [prog['fwd']])
+        grad = eng.store.grad
+        for sub, (b, e), holder in P['segs']:
+            eng._run_captured(holder, 'g', [sub])
             ev = torch.cuda.Event()
             ev.record(cur)
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(st.grad[b:e], op=dist.ReduceOp.SUM, group=eng.pg)
+                dist.all_reduce(grad[b:e], op=dist.ReduceOp.SUM, group=eng.pg)
         cur.wait_stream(self.comm_stream)
         lr = eng.optimizer_step()
         eng.refresh_shadows()
         return prog['dec'].loss, lr
-
-
-def holder_graph(P, i):
-    """Per-segment dict that _run_captured stores its hipGraph in."""
-    if P['graphs'][i] is None:
-        P['graphs'][i] = {}
-    return P['graphs'][i]
-
-
-def _lib_plan_slice(plan, start, stop):
-    from ._lib import Plan
-    sub = Plan()
-    sub.calls = plan.calls[start:stop]
-    sub._keep = plan._keep[start:stop]
-    return sub

@@ -83,7 +83,8 @@ class EncoderRunner:
                 if op.groups > 1:
                     part_rows = lib().capmi_bn_stats_part_rows(M, c, dtype_code)
                 else:
-                    part_rows = lib().capmi_igemm_nt_stats_part_rows(M, c, dtype_code)
+                    kk = self.kpad_of(op) if op.src == 0 else op.k * op.k * op.cin
+                    part_rows = lib().capmi_igemm_nt_stats_part_rows(M, c, kk, dtype_code)
                 nparts = (M + part_rows - 1) // part_rows
                 self.bn[op.dst] = dict(stats=z((nparts + 32, c, 2), torch.float32), part_rows=part_rows, mean=z((c,), torch.float32),
                                        invstd=z((c,), torch.float32), a=z((c,), torch.float32))
@@ -104,6 +105,10 @@ class EncoderRunner:
         self.out_id = enc.out
 
     # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def kpad_of(op):
+        return stem_kpad(op.k, op.cin)
+
     def _conv_geom(self, op):
         hi, wi, _ = self.shape[op.src]
         ho, wo, _ = self.shape[op.dst]

@@ -93,9 +93,18 @@ class CaptionEngine:
         self.shadow_plan = Plan()
         if self.code == BF16:
             self.shadow_plan.add('capmi_cast', _p(st.flat), _p(self.low), st.size, self.code)
+        # one launch for every data-gradient form: job table = one entry per 65536-element slice
+        jobs = []
         for name, (o, (n, kh, kw, c, ldt)) in self.wT_entries.items():
-            self.shadow_plan.add('capmi_weight_dgrad_form', _p(st.view(name)), _p(self.wT) + o * self.wT.element_size(),
-                                 n, kh, kw, c, ldt, self.code)
+            total = c * kh * kw * ldt
+            for first in range(0, total, 65536):
+                jobs.append((st.entries[name].offset, o, n, kh, kw, c, ldt, first))
+        table = np.zeros(len(jobs), dtype=np.dtype([('src', '<i8'), ('dst', '<i8'), ('N', '<i4'), ('kh', '<i4'), ('kw', '<i4'),
+                                                    ('C', '<i4'), ('ldt', '<i4'), ('first', '<i4')]))
+        for i, j in enumerate(jobs):
+            table[i] = j
+        self.dgrad_jobs = torch.from_numpy(table.view(np.uint8)).to(self.device)
+        self.shadow_plan.add('capmi_weight_dgrad_form_batched', _p(st.flat), _p(self.wT), _p(self.dgrad_jobs), len(jobs), self.code)
 
     def W(self, name):
         return self.store.view(name) if self.low is None else self.store.view(name, self.low)
@@ -174,11 +183,22 @@ class CaptionEngine:
                 p.run(self._stream())
             torch.cuda.synchronize(self.device)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                for p in plans:
-                    p.run(self._stream())
-            prog[key] = g
+            try:
+                # thread_local: other threads (e.g. the RCCL watchdog) may touch the runtime during capture
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                    for p in plans:
+                        p.run(self._stream())
+                prog[key] = g
+            except Exception as e:                    # stay on the HIP path, just without the graph
+                import sys
+                print('capmi: hipGraph capture failed (%s); replaying the launch plan eagerly' % e, file=sys.stderr)
+                torch.cuda.synchronize(self.device)
+                prog[key] = False
             return            # the warm-up run already produced this call's results
+        if prog[key] is False:
+            for p in plans:
+                p.run(self._stream())
+            return
         prog[key].replay()
 
     # ------------------------------------------------------------------ feeds

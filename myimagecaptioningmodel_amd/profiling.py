@@ -24,12 +24,17 @@ def _geom(arg):
     return g
 
 
-def _nt_tile(M, N, bf16):
+def _nt_tile(M, N, K, bf16):
+    """Mirror of nt_cfg() in csrc/igemm.hip (labels only)."""
+    cd = lambda x, y: -(-x // y)
     wide = N > 64
-    tall = -(-M // 128) * -(-N // (128 if wide else 64)) >= 256
     if bf16:
-        return (128, 128) if (wide and tall) else (64, 128) if wide else (128, 64) if tall else (64, 64)
-    return (64, 128) if wide else (128, 64) if tall else (64, 64)
+        if wide:
+            big = K >= 512 and cd(M, 128) * cd(N, 128) >= 512
+            return (128 if big else 64, 128)
+        return (128 if cd(M, 128) >= 512 else 64, 64)
+    tall = cd(M, 128) * cd(N, 64) >= 256
+    return (64, 128) if wide else ((128 if tall else 64), 64)
 
 
 def describe(name, args):
@@ -39,7 +44,10 @@ def describe(name, args):
         N, code, out_f32 = args[4], args[16], args[15]
         M, K = g.B * g.Ho * g.Wo, g.kh * g.kw * g.Cin
         es = 2 if code == BF16 else 4
-        bm, bn = _nt_tile(M, N, code == BF16)
+        bm, bn = _nt_tile(M, N, K, code == BF16)
+        plain = g.kh == 1 and g.kw == 1 and g.sd == 1 and g.up == 1 and g.pad == 0 and g.Hi == 1 and g.Wi == 1
+        if plain and not args[12] and M <= 64 and K % 128 == 0 and K >= 256:
+            return 'igemm_nt_skinny_kernel<%s>' % ('bf16' if code == BF16 else 'f32'), 2.0 * M * N * K, (M * K + N * K + M * N) * es
         # each input pixel / weight read once, output written once (im2col re-reads are on-chip)
         nbytes = g.B * g.Hi * g.Wi * g.Cin * es + N * K * es + M * N * (4 if out_f32 else es)
         if args[8]:

@@ -61,7 +61,8 @@ def check(got, want, dtype, scale=None, name=''):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-@pytest.mark.parametrize('M,N,K', [(64, 64, 32), (200, 72, 40), (130, 136, 104), (1216, 1000, 64), (37, 8, 16), (300, 260, 512)])
+@pytest.mark.parametrize('M,N,K', [(64, 64, 32), (200, 72, 40), (130, 136, 104), (1216, 1000, 64), (37, 8, 16), (300, 260, 512),
+                                   (64, 2048, 512), (64, 512, 2048), (37, 50, 256), (4, 136, 384)])
 def test_gemm_nt_epilogues(dtype, M, N, K):
     _lib, tdt, code = _env()
     rng = np.random.RandomState(M + N + K)
@@ -79,7 +80,7 @@ def test_gemm_nt_epilogues(dtype, M, N, K):
     check(host(Y), np.tanh(a @ w.T + bias), dtype, name='bias+tanh')
     # addend + dact + f32 output + stats
     Y32 = torch.zeros((M, N), dtype=torch.float32, device=DEV)
-    pr = _lib.lib().capmi_igemm_nt_stats_part_rows(M, N, code[dtype])
+    pr = _lib.lib().capmi_igemm_nt_stats_part_rows(M, N, K, code[dtype])
     nparts = (M + pr - 1) // pr
     stats = torch.full((nparts * N * 2,), float('nan'), dtype=torch.float32, device=DEV)
     _lib.call('capmi_igemm_nt', p(A), p(W), p(Y32), g, N, K, N, None, p(dev(add, tdt[dtype])), N, p(dev(ysaved, tdt[dtype])), N,
@@ -290,7 +291,7 @@ def test_batch_norm_statistics_no_cancellation():
     # the same through the GEMM epilogue: x = A . I
     eye = torch.eye(C, dtype=f32, device=DEV)
     Y = torch.zeros((M, C), dtype=f32, device=DEV)
-    pr2 = _lib.lib().capmi_igemm_nt_stats_part_rows(M, C, _lib.F32)
+    pr2 = _lib.lib().capmi_igemm_nt_stats_part_rows(M, C, C, _lib.F32)
     ws2 = torch.zeros((((M + pr2 - 1) // pr2 + 32) * C * 2,), dtype=f32, device=DEV)
     _lib.call('capmi_igemm_nt', p(X), p(eye), p(Y), _lib.gemm_geom(M, C), C, C, C, None, None, 0, None, 0, p(ws2), 0, 0, 0, _lib.F32, stream())
     _lib.call('capmi_bn_finalize', p(ws2), pr2, M, C, p(ones), None, None, 0.9, 1e-5, p(mean), p(invstd), p(ca), 0, stream())

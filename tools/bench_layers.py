@@ -62,7 +62,7 @@ for name, h, w, cin, cout, k, s, pad, ho, wo in rows:
     y = torch.zeros((B, ho, wo, cout), device=dev, dtype=bf)
     dx = torch.zeros((B, h, w, cin), device=dev, dtype=bf)
     dw = torch.zeros((cout, K), device=dev, dtype=torch.float32)
-    pr = _lib.lib().capmi_igemm_nt_stats_part_rows(M, cout, code)
+    pr = _lib.lib().capmi_igemm_nt_stats_part_rows(M, cout, K, code)
     ws = torch.zeros(((M + pr - 1) // pr + 32, cout, 2), device=dev, dtype=torch.float32)
     g = _lib.ConvGeom(B, h, w, cin, ho, wo, k, k, s, 1, pad, cin)
     gd = _lib.ConvGeom(B, ho, wo, cout, h, w, k, k, 1, s, k - 1 - pad, cout)
