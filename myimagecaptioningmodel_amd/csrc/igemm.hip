@@ -10,6 +10,20 @@
 // tile goes back through LDS so that every global store is a full 16-byte chunk of a row.
 #include "common.h"
 
+// floor(n / d) as (n * ceil(2^40 / d)) >> 40, exact whenever n * d < 2^40 (checked by the launchers):
+// one 64-bit multiply instead of a ~40-instruction integer division.
+struct FastDiv {
+    unsigned long long mul;
+    int d;
+};
+static FastDiv fast_div(int d) {
+    FastDiv f;
+    f.d = d;
+    f.mul = ((1ull << 40) + (unsigned long long)d - 1) / (unsigned long long)d;
+    return f;
+}
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) { return (int)(((unsigned long long)(unsigned)n * f.mul) >> 40); }
+
 struct IGemmArgs {
     const void* x;
     const void* w;
@@ -21,6 +35,7 @@ struct IGemmArgs {
     int M, N, K;
     int ldw, ldy, ld_addend, ld_saved;
     capmi_conv_geom g;
+    FastDiv fd_hw, fd_w;             // division by Ho*Wo and by Wo
     int act, dact, out_f32;
 #ifdef CAPMI_STAMPS
     unsigned long long* stamps;      // diagnostic build only: [workgroup][8] s_memtime stamps
@@ -75,14 +90,13 @@ struct RowPos {
     int64_t pix;      // b*Hi*Wi                        (up  > 1)
     bool ok;
 };
-__device__ __forceinline__ RowPos row_pos(int m, int M, const capmi_conv_geom& g) {
+__device__ __forceinline__ RowPos row_pos(int m, int M, const capmi_conv_geom& g, const FastDiv& dhw, const FastDiv& dw) {
     RowPos r;
     r.ok = m < M;
-    int hw = g.Ho * g.Wo;
-    int b = m / hw;
-    int rem = m - b * hw;
-    int ho = rem / g.Wo;
-    int wo = rem - ho * g.Wo;
+    int b = fdiv(m, dhw);
+    int rem = m - b * dhw.d;
+    int ho = fdiv(rem, dw);
+    int wo = rem - ho * dw.d;
     r.hb = ho * g.sd - g.pad;
     r.wb = wo * g.sd - g.pad;
     r.pix = (int64_t)b * g.Hi * g.Wi;
@@ -299,7 +313,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
 
     RowPos rp[ACH];
 #pragma unroll
-    for (int i = 0; i < ACH; ++i) rp[i] = row_pos(m0 + r0 + i * RSTEP, a.M, a.g);
+    for (int i = 0; i < ACH; ++i) rp[i] = row_pos(m0 + r0 + i * RSTEP, a.M, a.g, a.fd_hw, a.fd_w);
     KPos kp = k_pos(kc * VEC, a.g);
     int brow[BCH];                         // permuted LDS row of each W row this thread stages
 #pragma unroll
@@ -376,10 +390,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += bias;
         }
     }
-    if (a.stats && wcnt > 0) {
-        // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) of this wave's RW-row block
-        // per column, from the f32 accumulators; plain stores, one producer per (part, column):
-        // deterministic and cancellation-free (merged by bn_finalize, bn_ops.hip).
+    if (a.stats) {
+        // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) per column of this workgroup's
+        // BM-row block from the f32 accumulators.  Each wave reduces its RW rows in registers
+        // (two passes, no cancellation); the WMW wave results meet in LDS and are merged with Chan's
+        // formula; ONE part per workgroup row block is stored (plain stores, one producer per
+        // (part, column): deterministic).  bn_finalize (bn_ops.hip) merges the parts in f64.
+        float* sred = reinterpret_cast<float*>(As);          // [WMW][BN][2], the staging tiles are free now
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s1 = 0.f;
@@ -388,7 +406,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (rows_full || i * 16 + fg * 4 + r < wcnt) s1 += acc[i][j][r];
-            const float mean = row4_sum(s1) / (float)wcnt;
+            const float mean = wcnt > 0 ? row4_sum(s1) / (float)wcnt : 0.f;
             float m2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -398,11 +416,32 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
                     if (rows_full || i * 16 + fg * 4 + r < wcnt) m2 += d * d;
                 }
             m2 = row4_sum(m2);
-            if (fg == 0 && col0 + j < a.N) {
-                float* w = a.stats + ((int64_t)(wrow0 / RW) * a.N + col0 + j) * 2;
-                w[0] = mean;
-                w[1] = m2;
+            if (fg == 0) {
+                const int c = wn * WN + TN * fr + j;
+                sred[(wm * BN + c) * 2 + 0] = mean;
+                sred[(wm * BN + c) * 2 + 1] = m2;
             }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.N && m0 < a.M) {
+            float ntot = 0.f, msum = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) {
+                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
+                ntot += nw;
+                msum += nw * sred[(w * BN + tid) * 2];
+            }
+            const float mean = msum / ntot;
+            float m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) {
+                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
+                const float d = sred[(w * BN + tid) * 2] - mean;
+                m2 += sred[(w * BN + tid) * 2 + 1] + nw * d * d;
+            }
+            float* w = a.stats + ((int64_t)(m0 / BM) * a.N + n0 + tid) * 2;
+            w[0] = mean;
+            w[1] = m2;
         }
     }
     STAMP(4);
@@ -606,8 +645,7 @@ static NtCfg nt_cfg(int M, int N, int K, int dtype) {
 }
 
 extern "C" int capmi_igemm_nt_stats_part_rows(int M, int N, int K, int dtype) {
-    NtCfg c = nt_cfg(M, N, K, dtype);
-    return c.bm / c.wmw;
+    return nt_cfg(M, N, K, dtype).bm;
 }
 
 template <typename T, int BM, int BN, int WMW>
@@ -637,6 +675,8 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldw = ldw; a.ldy = ldy; a.ld_addend = ld_addend; a.ld_saved = ld_saved;
     a.g = *g; a.act = act; a.dact = dact; a.out_f32 = out_f32;
+    CAPMI_CHECK((long long)(a.M + 256) * g->Ho * g->Wo < (1ll << 40), "capmi_igemm_nt: M * Ho*Wo outside the fast-division range");
+    a.fd_hw = fast_div(g->Ho * g->Wo); a.fd_w = fast_div(g->Wo);
 #ifdef CAPMI_STAMPS
     a.stamps = g_stamp_buffer;
 #endif
@@ -675,6 +715,7 @@ struct WGradArgs {
     int m_per_split;
     int linear;       // 1x1 / stride 1 / no padding: A(m,k) = x[m*ldx + k]
     capmi_conv_geom g;
+    FastDiv fd_hw, fd_w;
 };
 
 // 8 reduction rows (8g..8g+7) x one column of a [rows][LD] LDS tile -> MFMA fragment.
@@ -697,15 +738,15 @@ __device__ __forceinline__ void load_frag_tr(Frag<float>& f, const float* tile, 
 
 template <typename T, int BNO, int BKO>
 __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
-    constexpr int RM = 32;                      // reduction rows per step
+    constexpr int RM = 64;                      // reduction rows per step: one LDS stage + one stage in registers
     constexpr int VEC = Vec<T>::N;
     constexpr int LDY = BNO + VEC, LDX = BKO + VEC;
     constexpr int CPY = BNO / VEC, CPX = BKO / VEC;        // chunks per row
     constexpr int YCH = RM * CPY / 256, XCH = RM * CPX / 256;
     static_assert(YCH >= 1 && XCH >= 1, "tile too small for 256 threads");
     constexpr int TN_ = BNO / 32, TK_ = BKO / 32;
-    __shared__ __attribute__((aligned(16))) T Ys[2][RM * LDY];
-    __shared__ __attribute__((aligned(16))) T Xs[2][RM * LDX];
+    __shared__ __attribute__((aligned(16))) T Ys[RM * LDY];
+    __shared__ __attribute__((aligned(16))) T Xs[RM * LDX];
 
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ DY = (const T*)a.dy;
@@ -723,30 +764,31 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
     constexpr int YRS = 256 / CPY, XRS = 256 / CPX;
     const KPos kp = k_pos(k0 + xc * VEC, a.g);      // this thread's k: fixed for the whole kernel
     const int ncol = n0 + yc * VEC;
+    const bool yok = ncol < a.N, xok = kp.k < a.K;
 
     Vec<T> ry[YCH], rx[XCH];
     auto load_tile = [&](int mt) {
 #pragma unroll
         for (int i = 0; i < YCH; ++i) {
             int m = mt + yr0 + i * YRS;
-            ry[i] = (m < m_end && ncol < a.N) ? vload<T>(DY + (int64_t)m * a.ldy + ncol) : vzero<T>();
+            ry[i] = (m < m_end && yok) ? vload<T>(DY + (int64_t)m * a.ldy + ncol) : vzero<T>();
         }
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
             int m = mt + xr0 + i * XRS;
             int64_t off = -1;
-            if (m < m_end) {
-                if (a.linear) off = kp.k < a.K ? (int64_t)m * a.g.ldx + kp.k : -1;
-                else off = a_offset(row_pos(m, a.M, a.g), kp, a.K, a.g);
+            if (m < m_end && xok) {
+                if (a.linear) off = (int64_t)m * a.g.ldx + kp.k;
+                else off = a_offset(row_pos(m, a.M, a.g, a.fd_hw, a.fd_w), kp, a.K, a.g);
             }
             rx[i] = off >= 0 ? vload<T>(X + off) : vzero<T>();
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < YCH; ++i) vstore<T>(&Ys[buf][(yr0 + i * YRS) * LDY + yc * VEC], ry[i]);
+        for (int i = 0; i < YCH; ++i) vstore<T>(&Ys[(yr0 + i * YRS) * LDY + yc * VEC], ry[i]);
 #pragma unroll
-        for (int i = 0; i < XCH; ++i) vstore<T>(&Xs[buf][(xr0 + i * XRS) * LDX + xc * VEC], rx[i]);
+        for (int i = 0; i < XCH; ++i) vstore<T>(&Xs[(xr0 + i * XRS) * LDX + xc * VEC], rx[i]);
     };
 
     f32x4 acc[TN_][TK_];
@@ -757,24 +799,23 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
 
     const int fr = lane & 15, fg = lane >> 4;
     load_tile(m_begin);
-    store_tile(0);
-    __syncthreads();
-    int buf = 0;
     for (int mt = m_begin; mt < m_end; mt += RM) {
-        const bool more = mt + RM < m_end;
-        if (more) load_tile(mt + RM);
-        Frag<T> af[TN_], bf[TK_];
-#pragma unroll
-        for (int i = 0; i < TN_; ++i) load_frag_tr(af[i], Ys[buf], LDY, fg, wn * (BNO / 2) + i * 16, fr);
-#pragma unroll
-        for (int j = 0; j < TK_; ++j) load_frag_tr(bf[j], Xs[buf], LDX, fg, wk * (BKO / 2) + j * 16, fr);
-#pragma unroll
-        for (int i = 0; i < TN_; ++i)
-#pragma unroll
-            for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[i], bf[j]);
-        if (more) store_tile(buf ^ 1);
+        if (mt != m_begin) __syncthreads();       // every wave is done reading the previous tile
+        store_tile();
         __syncthreads();
-        buf ^= 1;
+        if (mt + RM < m_end) load_tile(mt + RM);  // in flight during the MFMAs below
+#pragma unroll
+        for (int ks = 0; ks < RM / 32; ++ks) {
+            Frag<T> af[TN_], bf[TK_];
+#pragma unroll
+            for (int i = 0; i < TN_; ++i) load_frag_tr(af[i], Ys + ks * 32 * LDY, LDY, fg, wn * (BNO / 2) + i * 16, fr);
+#pragma unroll
+            for (int j = 0; j < TK_; ++j) load_frag_tr(bf[j], Xs + ks * 32 * LDX, LDX, fg, wk * (BKO / 2) + j * 16, fr);
+#pragma unroll
+            for (int i = 0; i < TN_; ++i)
+#pragma unroll
+                for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[i], bf[j]);
+        }
     }
     const bool single = gridDim.y == 1;           // sole contributor to its tile: plain read-modify-write
 #pragma unroll
@@ -810,7 +851,7 @@ static int launch_tn(WGradArgs& a, hipStream_t st) {
     if (max_splits > by_atomics) max_splits = (int)by_atomics;
     int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
     int per = cdiv(a.M, splits);
-    per = (per + 31) / 32 * 32;
+    per = (per + 63) / 64 * 64;
     splits = cdiv(a.M, per);
     a.m_per_split = per;
     hipLaunchKernelGGL((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles, splits), dim3(256), 0, st, a);
@@ -829,6 +870,8 @@ extern "C" int capmi_igemm_tn_wgrad(const void* x, const void* dy, float* dw, co
     a.x = x; a.dy = dy; a.dw = dw;
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldy = ldy; a.lddw = lddw; a.g = *g; a.m_per_split = a.M;
+    CAPMI_CHECK((long long)(a.M + 256) * g->Ho * g->Wo < (1ll << 40), "capmi_igemm_tn_wgrad: M * Ho*Wo outside the fast-division range");
+    a.fd_hw = fast_div(g->Ho * g->Wo); a.fd_w = fast_div(g->Wo);
     a.linear = (g->kh == 1 && g->kw == 1 && g->sd == 1 && g->up == 1 && g->pad == 0 && g->Hi == g->Ho && g->Wi == g->Wo) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const bool big = N >= 128 && a.K >= 128;
