@@ -39,6 +39,10 @@ typedef struct {
     int Ho, Wo;           /* output spatial size                                       */
     int kh, kw, sd, up, pad;
     int ldx;              /* elements between consecutive input pixels (>= Cin)        */
+    /* Output scatter (0/1 = dense): GEMM row (b,i,j) of the [B,Ho,Wo] grid is stored at pixel
+     * (b, i*os + oh0, j*os + ow0) of a [B,Hof,Wof] tensor -- one parity class of a strided
+     * convolution's data gradient.  addend / ysaved rows follow the same mapping. */
+    int os, oh0, ow0, Hof, Wof;
 } capmi_conv_geom;
 
 /* Y[m][n] = epilogue( sum_k A(m,k) * W[n][k] ),  m=(b,ho,wo), k=(r,q,c), A gathered by `g`.
@@ -204,8 +208,11 @@ int capmi_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr
 int capmi_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
 int capmi_weight_dgrad_form(const float* w, void* wt, int N, int kh, int kw, int C, int ldt, int dtype, void* stream);
 /* The same for every GEMM weight of a model in one launch.  jobs: device array of
- *   struct { int64 src_off, dst_off; int32 N, kh, kw, C, ldt, first; }   (40 bytes, one per 65536-
- * element slice of one weight's output; offsets in elements into `flat` (f32) / `shadow` (`dtype`)). */
+ *   struct { int64 src_off, dst_off; int32 N, kh, kw, C, ldt, first, okh, okw; int8 rmap[4], qmap[4]; }
+ * (56 bytes, one per 65536-element slice of one weight's output; offsets in elements into `flat`
+ * (f32) / `shadow` (`dtype`)).  Output is [C][okh][okw][ldt] with tap (r',q') taken from source tap
+ * (rmap[r'], qmap[q']): the plain data-gradient form is okh=kh, rmap[r'] = kh-1-r'; the parity
+ * classes of a strided convolution use a subset of the taps. */
 int capmi_weight_dgrad_form_batched(const float* flat, void* shadow, const void* jobs, int njobs, int dtype, void* stream);
 int capmi_fill_f32(float* p, float value, int64_t n, void* stream);
 

@@ -17,7 +17,7 @@ ACT_CODES = {None: ACT_NONE, 'relu': ACT_RELU, 'relu6': ACT_RELU6, 'tanh': ACT_T
 class ConvGeom(ctypes.Structure):
     """capmi_conv_geom (include/capmi.h)."""
     _fields_ = [(n, ctypes.c_int) for n in
-                ('B', 'Hi', 'Wi', 'Cin', 'Ho', 'Wo', 'kh', 'kw', 'sd', 'up', 'pad', 'ldx')]
+                ('B', 'Hi', 'Wi', 'Cin', 'Ho', 'Wo', 'kh', 'kw', 'sd', 'up', 'pad', 'ldx', 'os', 'oh0', 'ow0', 'Hof', 'Wof')]
 
 
 def gemm_geom(rows, K, ldx=None):

@@ -455,7 +455,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
             for (int r = 0; r < 4; ++r) {
                 const int rl = i * 16 + fg * 4 + r;
                 if (!rows_full && rl >= wcnt) continue;
-                const int64_t row = wrow0 + rl;
+                int64_t row = wrow0 + rl;
+                if (a.g.os > 1) {          // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
+                    const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
+                    const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
+                    row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
+                }
                 float v[TN], t[TN];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
@@ -670,6 +675,8 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
                 "capmi_igemm_nt: bad geometry (up must be a power of two)");
     CAPMI_CHECK(!dact || ysaved, "capmi_igemm_nt: dact needs ysaved");
     CAPMI_CHECK(!(stats && addend), "capmi_igemm_nt: fused statistics and addend are mutually exclusive");
+    CAPMI_CHECK(g->os <= 1 || (!stats && g->Hof > 0 && g->Wof > 0 && (g->Ho - 1) * g->os + g->oh0 < g->Hof && (g->Wo - 1) * g->os + g->ow0 < g->Wof),
+                "capmi_igemm_nt: bad output-scatter geometry");
     IGemmArgs a;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.addend = addend; a.ysaved = ysaved; a.stats = stats;
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
@@ -683,7 +690,7 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
     CAPMI_CHECK(ldw >= a.K, "capmi_igemm_nt: ldw=%d < K=%d", ldw, a.K);
     hipStream_t st = (hipStream_t)stream;
     const bool plain = g->kh == 1 && g->kw == 1 && g->sd == 1 && g->up == 1 && g->pad == 0 && g->Hi == 1 && g->Wi == 1 && g->Ho == 1 && g->Wo == 1;
-    if (plain && !stats && a.M <= 64 && a.K % 128 == 0 && a.K >= 256 && (dtype == CAPMI_BF16 || dtype == CAPMI_F32)) {
+    if (plain && g->os <= 1 && !stats && a.M <= 64 && a.K % 128 == 0 && a.K >= 256 && (dtype == CAPMI_BF16 || dtype == CAPMI_F32)) {
         // decoder recurrence and other M <= 64 products: skinny kernel (64x32 tiles, K split over waves)
         if (dtype == CAPMI_BF16) hipLaunchKernelGGL(igemm_nt_skinny_kernel<bf16>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(igemm_nt_skinny_kernel<float>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);

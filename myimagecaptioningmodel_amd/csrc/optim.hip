@@ -83,11 +83,13 @@ struct DgradJob {
     long long src_off, dst_off;     // element offsets into the f32 master / the shadow buffer
     int N, kh, kw, C, ldt;
     int first;                      // first output element of this slice
+    int okh, okw;                   // taps of the OUTPUT form
+    signed char rmap[4], qmap[4];   // output tap -> source tap
 };
 template <typename T>
 __global__ __launch_bounds__(256) void dgrad_form_batched_kernel(const float* __restrict__ flat, T* shadow, const DgradJob* __restrict__ jobs) {
     const DgradJob j = jobs[blockIdx.x];
-    const long long total = (long long)j.C * j.kh * j.kw * j.ldt;
+    const long long total = (long long)j.C * j.okh * j.okw * j.ldt;
     const float* w = flat + j.src_off;
     T* wt = shadow + j.dst_off;
     for (int e = threadIdx.x; e < 65536; e += 256) {
@@ -95,11 +97,11 @@ __global__ __launch_bounds__(256) void dgrad_form_batched_kernel(const float* __
         if (i >= total) break;
         int n = (int)(i % j.ldt);
         long long rest = i / j.ldt;
-        int q = (int)(rest % j.kw);
-        int r = (int)((rest / j.kw) % j.kh);
-        int c = (int)(rest / ((long long)j.kw * j.kh));
+        int q = (int)(rest % j.okw);
+        int r = (int)((rest / j.okw) % j.okh);
+        int c = (int)(rest / ((long long)j.okw * j.okh));
         float f = 0.f;
-        if (n < j.N) f = w[(((long long)n * j.kh + (j.kh - 1 - r)) * j.kw + (j.kw - 1 - q)) * j.C + c];
+        if (n < j.N) f = w[(((long long)n * j.kh + j.rmap[r]) * j.kw + j.qmap[q]) * j.C + c];
         wt[i] = from_f32<T>(f);
     }
 }

@@ -24,6 +24,41 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+def dgrad_classes(k, stride, pad):
+    """Output-parity classes of the data gradient of a k x k / stride-s / pad-p convolution.
+    Input pixel hi = s*i + ph receives tap r from output row ho = (hi + p - r)/s only when
+    s | (hi + p - r): per class (ph, pw) the taps form a DENSE small convolution over the compact
+    [ceil((H-ph)/s)] grid.  Returns [(ph, pw, rmap, qmap)]: class tap r' (offset ho - i = r' - lo)
+    reads source tap rmap[r']; classes without taps (no gradient reaches them) are omitted."""
+    def taps(ph):
+        # valid source taps r with (ph + pad - r) % stride == 0, as offsets d = (ph + pad - r)/stride
+        offs = sorted(((ph + pad - r) // stride, r) for r in range(k) if (ph + pad - r) % stride == 0)
+        return offs          # [(d, r)] ascending d: ho = i + d
+    out = []
+    for ph in range(stride):
+        th = taps(ph)
+        if not th:
+            continue
+        for pw in range(stride):
+            tw = taps(pw)
+            if not tw:
+                continue
+            out.append((ph, pw, [r for _, r in th], [q for _, q in tw], th[0][0], tw[0][0]))
+    return [(ph, pw, rm, qm) for ph, pw, rm, qm, _, _ in out]
+
+
+def dgrad_class_offsets(k, stride, pad):
+    """First row/col offset d0 (ho = i + d0 + r') of each class, keyed (ph, pw)."""
+    res = {}
+    for ph in range(stride):
+        oh = sorted((ph + pad - r) // stride for r in range(k) if (ph + pad - r) % stride == 0)
+        for pw in range(stride):
+            ow = sorted((pw + pad - q) // stride for q in range(k) if (pw + pad - q) % stride == 0)
+            if oh and ow:
+                res[(ph, pw)] = (oh[0], ow[0], len(oh), len(ow))
+    return res
+
+
 class EncoderRunner:
     def __init__(self, store, B, S, dtype_code, torch_dtype, need_backward):
         self.store, self.enc = store, store.enc
@@ -222,10 +257,28 @@ class EncoderRunner:
                     plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(self.draw), _p(dwt), g, c, c, K, code)
                     dx = self.grad[op.src]
                     acc = op.src in written
-                    gd = self._dgrad_geom(op)
-                    Kd = op.k * op.k * op.cout
-                    plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd(op.name + '_weights')), _p(dx), gd, op.cin, Kd, op.cin,
-                             None, _p(dx) if acc else None, op.cin, None, 0, None, 0, 0, 0, code)
+                    if op.stride == 1:
+                        gd = self._dgrad_geom(op)
+                        Kd = op.k * op.k * op.cout
+                        plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd(op.name + '_weights')), _p(dx), gd, op.cin, Kd, op.cin,
+                                 None, _p(dx) if acc else None, op.cin, None, 0, None, 0, 0, 0, code)
+                    else:
+                        # strided conv: one dense GEMM per output-parity class over the compact grid,
+                        # rows scattered to pixels (s*i+ph, s*j+pw) -- no MFMA on structural zeros
+                        hi, wi, _ = self.shape[op.src]
+                        classes = dgrad_class_offsets(op.k, op.stride, op.pad)
+                        covered = len(classes) == op.stride * op.stride
+                        if not covered and not acc:      # some pixels get no gradient: start from zero
+                            plan.add('capmi_fill_f32', _p(dx), 0.0, dx.numel() * dx.element_size() // 4)
+                            acc = True
+                        for (ph, pw), (d0h, d0w, nkh, nkw) in classes.items():
+                            hc, wc = (hi - ph + op.stride - 1) // op.stride, (wi - pw + op.stride - 1) // op.stride
+                            # ho = i + d0h + r'  <=>  hn = i*1 - pad' + r' with pad' = -d0h
+                            gd = ConvGeom(B, ho, wo, op.cout, hc, wc, nkh, nkw, 1, 1, -d0h, op.cout, op.stride, ph, pw, hi, wi)
+                            if d0h != d0w:
+                                raise NotImplementedError('asymmetric parity classes')
+                            plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd((op.name + '_weights', ph, pw))), _p(dx), gd, op.cin,
+                                     nkh * nkw * op.cout, op.cin, None, _p(dx) if acc else None, op.cin, None, 0, None, 0, 0, 0, code)
                     written.add(op.src)
                 if segments is not None:
                     segments.append((len(plan), op.name))

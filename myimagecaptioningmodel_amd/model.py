@@ -75,7 +75,18 @@ class CaptionEngine:
         self.wT_entries = {}
         off = 0
         V, E = self.cfg['vocab'], self.cfg['embed']
+        strides = {op.name + '_weights': op.stride for op in st.enc.ops if hasattr(op, 'stride')}
         for name, e in st.entries.items():
+            if e.kind == 'conv' and strides.get(name, 1) > 1:
+                # strided conv: one weight form per output-parity class of its data gradient (see
+                # encoder.dgrad_classes); key = (name, ph, pw)
+                from .encoder import dgrad_classes
+                n, kh, kw, c = e.kshape
+                for (ph, pw, rmap, qmap) in dgrad_classes(kh, strides[name], (kh - 1) // 2):
+                    size = c * len(rmap) * len(qmap) * n
+                    self.wT_entries[(name, ph, pw)] = (off, (n, kh, kw, c, n), rmap, qmap)
+                    off += (size + 7) // 8 * 8
+                continue
             if e.kind == 'conv':
                 n, kh, kw, c = e.kshape
                 spec = (n, kh, kw, c, n)
@@ -87,7 +98,7 @@ class CaptionEngine:
             else:
                 continue
             size = spec[3] * spec[1] * spec[2] * spec[4]
-            self.wT_entries[name] = (off, spec)
+            self.wT_entries[name] = (off, spec, [spec[1] - 1 - r for r in range(spec[1])], [spec[2] - 1 - q for q in range(spec[2])])
             off += (size + 7) // 8 * 8
         self.wT = torch.zeros(off, dtype=self.tdt, device=self.device)
         self.shadow_plan = Plan()
@@ -95,12 +106,16 @@ class CaptionEngine:
             self.shadow_plan.add('capmi_cast', _p(st.flat), _p(self.low), st.size, self.code)
         # one launch for every data-gradient form: job table = one entry per 65536-element slice
         jobs = []
-        for name, (o, (n, kh, kw, c, ldt)) in self.wT_entries.items():
-            total = c * kh * kw * ldt
+        for key, (o, (n, kh, kw, c, ldt), rmap, qmap) in self.wT_entries.items():
+            name = key if isinstance(key, str) else key[0]
+            total = c * len(rmap) * len(qmap) * ldt
             for first in range(0, total, 65536):
-                jobs.append((st.entries[name].offset, o, n, kh, kw, c, ldt, first))
+                jobs.append((st.entries[name].offset, o, n, kh, kw, c, ldt, first, len(rmap), len(qmap),
+                             (list(rmap) + [0] * 4)[:4], (list(qmap) + [0] * 4)[:4]))
         table = np.zeros(len(jobs), dtype=np.dtype([('src', '<i8'), ('dst', '<i8'), ('N', '<i4'), ('kh', '<i4'), ('kw', '<i4'),
-                                                    ('C', '<i4'), ('ldt', '<i4'), ('first', '<i4')]))
+                                                    ('C', '<i4'), ('ldt', '<i4'), ('first', '<i4'), ('okh', '<i4'), ('okw', '<i4'),
+                                                    ('rmap', 'i1', (4,)), ('qmap', 'i1', (4,))]))
+        assert table.dtype.itemsize == 56
         for i, j in enumerate(jobs):
             table[i] = j
         self.dgrad_jobs = torch.from_numpy(table.view(np.uint8)).to(self.device)
@@ -109,9 +124,10 @@ class CaptionEngine:
     def W(self, name):
         return self.store.view(name) if self.low is None else self.store.view(name, self.low)
 
-    def WT(self, name):
-        o, (n, kh, kw, c, ldt) = self.wT_entries[name]
-        return self.wT[o:o + c * kh * kw * ldt]
+    def WT(self, key):
+        """Data-gradient form of weight `key` (a name, or (name, ph, pw) for a parity class of a strided conv)."""
+        o, (n, kh, kw, c, ldt), rmap, qmap = self.wT_entries[key]
+        return self.wT[o:o + c * len(rmap) * len(qmap) * ldt]
 
     def refresh_shadows(self):
         self.shadow_plan.run(self._stream())

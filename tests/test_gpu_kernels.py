@@ -142,6 +142,38 @@ def test_conv_fwd_dgrad_wgrad(dtype, B, C, H, W, Co, k, s, pad):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('B,C,H,W,Co,k,pad', [(2, 16, 12, 10, 24, 3, 1), (3, 8, 9, 11, 16, 3, 1), (2, 32, 8, 8, 16, 1, 0), (2, 16, 7, 9, 8, 1, 0)])
+def test_strided_dgrad_by_parity_classes(dtype, B, C, H, W, Co, k, pad):
+    """Data gradient of a stride-2 conv as dense GEMMs per output-parity class, rows scattered to the
+    strided pixels (what encoder.plan_backward launches) == the oracle's conv2d_bwd."""
+    _lib, tdt, code = _env()
+    from myimagecaptioningmodel_amd.encoder import dgrad_classes, dgrad_class_offsets
+    s = 2
+    rng = np.random.RandomState(B * C + Co + k)
+    x = rnd(rng.standard_normal((B, C, H, W)), dtype)
+    w = rnd(rng.standard_normal((Co, C, k, k)) / np.sqrt(C * k * k), dtype)
+    y = O.conv2d_fwd(x, w, s, pad)
+    Ho, Wo = y.shape[2:]
+    dy = rnd(rng.standard_normal(y.shape), dtype)
+    dx, _ = O.conv2d_bwd(dy, x, w, s, pad)
+    DY = dev(_nhwc(dy), tdt[dtype])
+    base = rnd(rng.standard_normal((B, H, W, C)), dtype)          # pre-existing gradient: accumulate form
+    DX = dev(base, tdt[dtype]).clone()
+    offs = dgrad_class_offsets(k, s, pad)
+    for (ph, pw, rmap, qmap) in dgrad_classes(k, s, pad):
+        d0h, d0w, nkh, nkw = offs[(ph, pw)]
+        wc = np.zeros((C, nkh, nkw, Co))
+        for a_, r in enumerate(rmap):
+            for b_, q in enumerate(qmap):
+                wc[:, a_, b_, :] = w[:, :, r, q].T
+        hc, wcc = (H - ph + s - 1) // s, (W - pw + s - 1) // s
+        gd = _lib.ConvGeom(B, Ho, Wo, Co, hc, wcc, nkh, nkw, 1, 1, -d0h, Co, s, ph, pw, H, W)
+        _lib.call('capmi_igemm_nt', p(DY), p(dev(wc, tdt[dtype])), p(DX), gd, C, nkh * nkw * Co, C, None, p(DX), C, None, 0, None, 0, 0, 0,
+                  code[dtype], stream())
+    check(host(DX), base + _nhwc(dx), dtype, name='strided dgrad (accumulate)')
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(1216, 40, 48), (64, 264, 136), (5000, 16, 24), (333, 1000, 32)])
 def test_fc_wgrad_and_colsum(dtype, M, N, K):
     _lib, tdt, code = _env()

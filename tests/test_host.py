@@ -59,7 +59,7 @@ def test_argument_errors_are_reported_not_thrown():
     g = _lib.gemm_geom(4, 12)                      # K=12 is not a multiple of the 8-element bf16 vector
     rc = L.capmi_igemm_nt(1, 1, 1, g, 8, 12, 8, None, None, 0, None, 0, None, 0, 0, 0, _lib.BF16, None)
     assert rc != 0 and b'multiples' in L.capmi_last_error()
-    assert L.capmi_igemm_nt_stats_part_rows(200704, 64, 64, _lib.BF16) in (16, 32, 64)
+    assert L.capmi_igemm_nt_stats_part_rows(200704, 64, 64, _lib.BF16) in (64, 128)   # one part per workgroup row block
 
 
 def test_engine_refuses_to_run_without_a_gpu():
