@@ -57,7 +57,7 @@ def pmc_traffic(label):
         pre = '_Z15%sI%sLi%sELi%sE' % (m.group(1), 'DF16b' if m.group(3) == 'bf16' else 'f', m.group(4), m.group(5))
         hit = [v for k, v in kernels.items() if k.startswith(pre)]
     else:
-        hit = [v for k, v in kernels.items() if label in k]
+        hit = [v for k, v in kernels.items() if label.replace('_kernel', '') in k]
     return round(hit[0]['hbm_bytes_per_launch'] / 1e6, 3) if hit else None       # MB per launch
 
 

@@ -64,11 +64,16 @@ int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom*
                    const void* ysaved, int ld_saved, float* stats,
                    int act, int dact, int out_f32, int dtype, void* stream);
 
-/* dW[n][k] (+)= sum_m dY[m][n] * A(m,k): weight gradient (f32 output, atomic accumulation --
- * the caller zeroes dW once per step).  Replaces conv2d_grad's filter gradient and mul_grad's
- * weight gradient for the same call sites as capmi_igemm_nt.  dY is [M][ldy] in `dtype`. */
+/* dW[n][k] += sum_m dY[m][n] * A(m,k): weight gradient (f32 output; the caller zeroes dW once per
+ * step).  The pixel axis is split over workgroups; each split stores its partial tile to the f32
+ * workspace `ws` (capmi_igemm_tn_ws_bytes(M,N,K,dtype) bytes; 0 = not needed) and a second kernel
+ * sums the splits in fixed order (deterministic); outputs smaller than a 128x128 tile use f32
+ * atomics instead.  Replaces conv2d_grad's filter
+ * gradient and mul_grad's weight gradient for the same call sites as capmi_igemm_nt.
+ * dY is [M][ldy] in `dtype`. */
+long long capmi_igemm_tn_ws_bytes(int M, int N, int K, int dtype);
 int capmi_igemm_tn_wgrad(const void* x, const void* dy, float* dw, const capmi_conv_geom* g,
-                         int N, int ldy, int lddw, int dtype, void* stream);
+                         int N, int ldy, int lddw, float* ws, long long ws_bytes, int dtype, void* stream);
 
 /* out[n] += sum_m a[m][n] (f32 atomic accumulate): bias gradients (elementwise_add_grad). */
 int capmi_colsum(const void* a, int M, int N, int lda, float* out, int dtype, void* stream);

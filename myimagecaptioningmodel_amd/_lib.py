@@ -31,7 +31,7 @@ _g = ctypes.POINTER(ConvGeom)
 # name -> argument ctypes (the trailing `void* stream` included).  Must list every symbol of capmi.h.
 SIGNATURES = {
     'capmi_igemm_nt': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
-    'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _i, _p],
+    'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
     'capmi_colsum': [_p, _i, _i, _i, _p, _i, _p],
     'capmi_im2col_stem': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_dwconv3x3_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -105,6 +105,8 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = ctypes.c_int
+        L.capmi_igemm_tn_ws_bytes.argtypes = [_i, _i, _i, _i]
+        L.capmi_igemm_tn_ws_bytes.restype = ctypes.c_longlong
         _lib = L
     return _lib
 
@@ -118,6 +120,20 @@ def call(name, *args):
     rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise CapmiError('%s failed (%d): %s' % (name, rc, last_error()))
+
+
+WGRAD_WS_BYTES = 32 << 20      # >= any capmi_igemm_tn_ws_bytes() result (partial slabs are capped at 24 MiB)
+_wgrad_ws = {}
+
+
+def wgrad_workspace(device):
+    """One shared f32 scratch buffer per device for the weight-gradient partial slabs (launches on
+    one stream run in order, so they can share it)."""
+    import torch
+    key = str(device)
+    if key not in _wgrad_ws:
+        _wgrad_ws[key] = torch.zeros(WGRAD_WS_BYTES // 4, dtype=torch.float32, device=device)
+    return _wgrad_ws[key]
 
 
 class Plan:

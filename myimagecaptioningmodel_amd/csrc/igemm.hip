@@ -276,6 +276,138 @@ template <int TN> __device__ __forceinline__ void dact_run(float (&v)[TN], const
     }
 }
 
+// ------------------------------------------------------------------ shared epilogue of the tiled NT kernels
+template <typename T, int BM, int BN, int WMW>
+__device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred) {
+    constexpr int WNW = 4 / WMW, RW = BM / WMW, WN = BN / WNW, TM = RW / 16, TN = WN / 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int fr = lane & 15, fg = lane >> 4;
+    // ---- epilogue (registers only).  acc[i][j][r] = output (row wrow0 + 16i + 4fg + r, column col0 + j).
+    const int wrow0 = m0 + wm * RW;                            // first row of this wave's sub-tile
+    const int wcnt = min(RW, a.M - wrow0);                     // valid rows in it (<= 0: none)
+    const int col0 = n0 + wn * WN + TN * fr;                   // this lane's TN consecutive columns
+    const bool rows_full = wcnt == RW;
+    if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float bias = col0 + j < a.N ? a.bias[col0 + j] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += bias;
+        }
+    }
+    if (a.stats) {
+        // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) per column of this workgroup's
+        // BM-row block from the f32 accumulators.  Each wave reduces its RW rows in registers
+        // (two passes, no cancellation); the WMW wave results meet in LDS and are merged with Chan's
+        // formula; ONE part per workgroup row block is stored (plain stores, one producer per
+        // (part, column): deterministic).  bn_finalize (bn_ops.hip) merges the parts in f64.
+        // sred: [WMW][BN][2] floats of LDS scratch (the staging tiles are free now)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rows_full || i * 16 + fg * 4 + r < wcnt) s1 += acc[i][j][r];
+            const float mean = wcnt > 0 ? row4_sum(s1) / (float)wcnt : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = acc[i][j][r] - mean;
+                    if (rows_full || i * 16 + fg * 4 + r < wcnt) m2 += d * d;
+                }
+            m2 = row4_sum(m2);
+            if (fg == 0) {
+                const int c = wn * WN + TN * fr + j;
+                sred[(wm * BN + c) * 2 + 0] = mean;
+                sred[(wm * BN + c) * 2 + 1] = m2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.N && m0 < a.M) {
+            float ntot = 0.f, msum = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) {
+                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
+                ntot += nw;
+                msum += nw * sred[(w * BN + tid) * 2];
+            }
+            const float mean = msum / ntot;
+            float m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) {
+                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
+                const float d = sred[(w * BN + tid) * 2] - mean;
+                m2 += sred[(w * BN + tid) * 2 + 1] + nw * d * d;
+            }
+            float* w = a.stats + ((int64_t)(m0 / BM) * a.N + n0 + tid) * 2;
+            w[0] = mean;
+            w[1] = m2;
+        }
+    }
+    const T* addend = (const T*)a.addend;
+    const T* ysaved = (const T*)a.ysaved;
+    const bool vec_ok = (a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N;
+    if (col0 < a.N) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rl = i * 16 + fg * 4 + r;
+                if (!rows_full && rl >= wcnt) continue;
+                int64_t row = wrow0 + rl;
+                if (a.g.os > 1) {          // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
+                    const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
+                    const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
+                    row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
+                }
+                float v[TN], t[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
+                if (vec_ok) {
+                    if (addend) {
+                        load_run<T, TN>(addend + row * a.ld_addend + col0, t);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) v[j] += t[j];
+                    }
+                    act_run<TN>(v, a.act);
+                    if (a.dact) {
+                        load_run<T, TN>(ysaved + row * a.ld_saved + col0, t);
+                        dact_run<TN>(v, t, a.dact);
+                    }
+                    if (a.out_f32) store_run<float, TN>((float*)a.y + row * a.ldy + col0, v);
+                    else store_run<T, TN>((T*)a.y + row * a.ldy + col0, v);
+                } else {
+                    const int nv = min(TN, a.N - col0);
+                    if (addend) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) v[j] += j < nv ? to_f32(addend[row * a.ld_addend + col0 + j]) : 0.f;
+                    }
+                    act_run<TN>(v, a.act);
+                    if (a.dact) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) t[j] = j < nv ? to_f32(ysaved[row * a.ld_saved + col0 + j]) : 0.f;
+                        dact_run<TN>(v, t, a.dact);
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (j < nv) {
+                            if (a.out_f32) ((float*)a.y)[row * a.ldy + col0 + j] = v[j];
+                            else ((T*)a.y)[row * a.ldy + col0 + j] = from_f32<T>(v[j]);
+                        }
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ NT kernel
 // Column permutation: the weight row fed to MFMA tile j, lane fr of a wave is column TN*fr + j of
 // the wave's BN/2-column range (the permutation is applied when the W tile is written to LDS, so
@@ -375,135 +507,119 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
     }
 
     STAMP(3);
-    // ---- epilogue (registers only).  acc[i][j][r] = output (row wrow0 + 16i + 4fg + r, column col0 + j).
-    const int wrow0 = m0 + wm * RW;                            // first row of this wave's sub-tile
-    const int wcnt = min(RW, a.M - wrow0);                     // valid rows in it (<= 0: none)
-    const int col0 = n0 + wn * WN + TN * fr;                   // this lane's TN consecutive columns
-    const bool rows_full = wcnt == RW;
-    if (a.bias) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float bias = col0 + j < a.N ? a.bias[col0 + j] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] += bias;
-        }
-    }
-    if (a.stats) {
-        // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) per column of this workgroup's
-        // BM-row block from the f32 accumulators.  Each wave reduces its RW rows in registers
-        // (two passes, no cancellation); the WMW wave results meet in LDS and are merged with Chan's
-        // formula; ONE part per workgroup row block is stored (plain stores, one producer per
-        // (part, column): deterministic).  bn_finalize (bn_ops.hip) merges the parts in f64.
-        float* sred = reinterpret_cast<float*>(As);          // [WMW][BN][2], the staging tiles are free now
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (rows_full || i * 16 + fg * 4 + r < wcnt) s1 += acc[i][j][r];
-            const float mean = wcnt > 0 ? row4_sum(s1) / (float)wcnt : 0.f;
-            float m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d = acc[i][j][r] - mean;
-                    if (rows_full || i * 16 + fg * 4 + r < wcnt) m2 += d * d;
-                }
-            m2 = row4_sum(m2);
-            if (fg == 0) {
-                const int c = wn * WN + TN * fr + j;
-                sred[(wm * BN + c) * 2 + 0] = mean;
-                sred[(wm * BN + c) * 2 + 1] = m2;
-            }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < a.N && m0 < a.M) {
-            float ntot = 0.f, msum = 0.f;
-#pragma unroll
-            for (int w = 0; w < WMW; ++w) {
-                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
-                ntot += nw;
-                msum += nw * sred[(w * BN + tid) * 2];
-            }
-            const float mean = msum / ntot;
-            float m2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WMW; ++w) {
-                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
-                const float d = sred[(w * BN + tid) * 2] - mean;
-                m2 += sred[(w * BN + tid) * 2 + 1] + nw * d * d;
-            }
-            float* w = a.stats + ((int64_t)(m0 / BM) * a.N + n0 + tid) * 2;
-            w[0] = mean;
-            w[1] = m2;
-        }
-    }
-    STAMP(4);
-    const T* addend = (const T*)a.addend;
-    const T* ysaved = (const T*)a.ysaved;
-    const bool vec_ok = (a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N;
-    if (col0 < a.N) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rl = i * 16 + fg * 4 + r;
-                if (!rows_full && rl >= wcnt) continue;
-                int64_t row = wrow0 + rl;
-                if (a.g.os > 1) {          // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
-                    const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
-                    const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
-                    row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
-                }
-                float v[TN], t[TN];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
-                if (vec_ok) {
-                    if (addend) {
-                        load_run<T, TN>(addend + row * a.ld_addend + col0, t);
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) v[j] += t[j];
-                    }
-                    act_run<TN>(v, a.act);
-                    if (a.dact) {
-                        load_run<T, TN>(ysaved + row * a.ld_saved + col0, t);
-                        dact_run<TN>(v, t, a.dact);
-                    }
-                    if (a.out_f32) store_run<float, TN>((float*)a.y + row * a.ldy + col0, v);
-                    else store_run<T, TN>((T*)a.y + row * a.ldy + col0, v);
-                } else {
-                    const int nv = min(TN, a.N - col0);
-                    if (addend) {
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) v[j] += j < nv ? to_f32(addend[row * a.ld_addend + col0 + j]) : 0.f;
-                    }
-                    act_run<TN>(v, a.act);
-                    if (a.dact) {
-#pragma unroll
-                        for (int j = 0; j < TN; ++j) t[j] = j < nv ? to_f32(ysaved[row * a.ld_saved + col0 + j]) : 0.f;
-                        dact_run<TN>(v, t, a.dact);
-                    }
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (j < nv) {
-                            if (a.out_f32) ((float*)a.y)[row * a.ldy + col0 + j] = v[j];
-                            else ((T*)a.y)[row * a.ldy + col0 + j] = from_f32<T>(v[j]);
-                        }
-                }
-            }
-        }
-    }
+    nt_epilogue<T, BM, BN, WMW>(a, acc, m0, n0, reinterpret_cast<float*>(As));
     STAMP(5);
 #ifdef CAPMI_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(6);
 #endif
+}
+
+// ------------------------------------------------------------------ NT kernel, LDS-DMA pipeline (bf16, deep K)
+// 128x128x32 tiles, a ring of 4 LDS stages filled by global_load_lds (no staging VGPRs): three
+// stages (48 KB per workgroup) are in flight while one is being multiplied.  A wave-instruction of
+// the DMA writes 1 KiB of LDS linearly (wave-uniform base + lane*16), so the tile rows are stored
+// unpadded (64 B) and the ds_read_b128 bank conflicts are removed by an XOR swizzle applied on the
+// SOURCE side: LDS slot (row, p) receives global chunk p ^ ((row >> 2) & 3), and fragment reads use
+// the same involution.  Padding taps / out-of-range rows read a 64-byte zero page.  Counted
+// s_waitcnt vmcnt(8) (two younger stages stay in flight) + ONE raw s_barrier per k-tile; no
+// __syncthreads() in the loop (it would drain the DMA queue).
+__device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
+
+__global__ __launch_bounds__(256) void igemm_nt_glds_kernel(IGemmArgs a) {
+    typedef bf16 T;
+    constexpr int BM = 128, BN = 128, BK = 32, NST = 4, WMW = 4;
+    constexpr int TM = 2, TN = 8;                       // 4x1 waves: 32 rows x 128 columns each
+    constexpr int OPB = BM * BK * 2;                    // bytes of one operand tile (8 KiB)
+    constexpr int STB = 2 * OPB;                        // bytes per stage
+    __shared__ __attribute__((aligned(1024))) char smem[NST * STB];
+
+    const T* __restrict__ X = (const T*)a.x;
+    const T* __restrict__ W = (const T*)a.w;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int m0 = (tile / tiles_n) * BM;
+    const int n0 = (tile % tiles_n) * BN;
+
+    // this thread's two DMA slots per operand tile: rows (tid>>2) and 64 + (tid>>2), LDS chunk position
+    // tid&3, i.e. global chunk (tid&3) ^ ((tid>>4)&3) of that row ((row>>2)&3 is the same for both rows)
+    const int chunk = (tid & 3) ^ ((tid >> 4) & 3);
+    RowPos rp[2];
+    const T* wrow[2];
+    bool wok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int l = i * 64 + (tid >> 2);
+        rp[i] = row_pos(m0 + l, a.M, a.g, a.fd_hw, a.fd_w);
+        const int n = n0 + 8 * (l & 15) + (l >> 4);     // LDS row j*16+fr holds weight column TN*fr + j
+        wok[i] = n < a.N;
+        wrow[i] = W + (int64_t)(wok[i] ? n : 0) * a.ldw;
+    }
+    KPos kp = k_pos(chunk * 8, a.g);
+    const T* zero = reinterpret_cast<const T*>(capmi_zero_page);
+
+    auto issue_stage = [&](int st) {    // DMA of the tile at the current kp into ring slot st; advances kp
+        char* base = smem + st * STB + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t off = a_offset(rp[i], kp, a.K, a.g);
+            const T* src = off >= 0 ? X + off : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const T* src = (wok[i] && kp.k < a.K) ? wrow[i] + kp.k : zero;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + OPB + i * 4096), 16, 0, 0);
+        }
+        k_advance(kp, BK, a.g);
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (a.K + BK - 1) / BK;
+    const int fr = lane & 15, fg = lane >> 4;
+    // fragment byte offsets inside an operand tile (swizzled chunk position)
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = wave * 32 + i * 16 + fr;
+        aoff[i] = row * 64 + ((fg ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = j * 16 + fr;
+        boff[j] = OPB + row * 64 + ((fg ^ ((row >> 2) & 3)) << 4);
+    }
+
+    issue_stage(0);
+    issue_stage(1);
+    issue_stage(2);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this thread's part of stage kt has landed
+        __builtin_amdgcn_s_barrier();                        // ... and everyone else's; all waves left stage kt-1
+        asm volatile("" ::: "memory");
+        issue_stage((kt + 3) & 3);                           // refill the slot that was read in iteration kt-1
+        const char* st = smem + (kt & 3) * STB;
+        Frag<T> af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i].load(reinterpret_cast<const T*>(st + aoff[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j].load(reinterpret_cast<const T*>(st + boff[j]));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mma16(acc[i][j], af[i], bf[j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the (zero-page) tail stages before LDS reuse
+    __syncthreads();
+    nt_epilogue<T, BM, BN, WMW>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
 }
 
 // ------------------------------------------------------------------ skinny NT kernel (M <= 64)
@@ -639,7 +755,7 @@ static NtCfg nt_cfg(int M, int N, int K, int dtype) {
     const bool wide = N > 64;
     if (dtype == CAPMI_BF16) {
         if (wide) {
-            const bool big = K >= 512 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 512;
+            const bool big = K >= 512 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 384;   // LDS-DMA pipeline kernel: deep K, full grid
             return NtCfg{big ? 128 : 64, 128, 4};
         }
         const bool tall = cdiv(M, 128) >= 512;
@@ -699,7 +815,12 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
     }
     const NtCfg c = nt_cfg(a.M, N, a.K, dtype);
     if (dtype == CAPMI_BF16) {
-        if (c.bm == 128 && c.bn == 128) return launch_nt<bf16, 128, 128, 4>(a, st);
+        if (c.bm == 128 && c.bn == 128) {
+            const int64_t tiles = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
+            hipLaunchKernelGGL(igemm_nt_glds_kernel, dim3((unsigned)tiles), dim3(256), 0, st, a);
+            CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
+            return 0;
+        }
         if (c.bm == 64 && c.bn == 128) return launch_nt<bf16, 64, 128, 4>(a, st);
         if (c.bm == 128 && c.bn == 64) return launch_nt<bf16, 128, 64, 4>(a, st);
         return launch_nt<bf16, 64, 64, 4>(a, st);
@@ -721,6 +842,8 @@ struct WGradArgs {
     int ldy, lddw;
     int m_per_split;
     int linear;       // 1x1 / stride 1 / no padding: A(m,k) = x[m*ldx + k]
+    float* slab;      // [splits][Kp][Np] f32 partial tiles (transposed), or NULL: add straight into dw
+    int Np, Kp;
     capmi_conv_geom g;
     FastDiv fd_hw, fd_w;
 };
@@ -824,7 +947,20 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
                 for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[i], bf[j]);
         }
     }
-    const bool single = gridDim.y == 1;           // sole contributor to its tile: plain read-modify-write
+    if (a.slab) {
+        // partial tile -> slab[split][k][n] (transposed): the accumulator quad of a lane is 4
+        // consecutive n of one k, i.e. one 16-byte store; no atomics (wgrad_reduce_kernel sums the splits)
+        float* sl = a.slab + (size_t)blockIdx.y * a.Kp * a.Np;
+#pragma unroll
+        for (int i = 0; i < TN_; ++i)
+#pragma unroll
+            for (int j = 0; j < TK_; ++j) {
+                const int k = k0 + wk * (BKO / 2) + j * 16 + fr;
+                const int n = n0 + wn * (BNO / 2) + i * 16 + fg * 4;
+                *reinterpret_cast<f32x4*>(&sl[(size_t)k * a.Np + n]) = acc[i][j];
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TN_; ++i)
 #pragma unroll
@@ -835,39 +971,89 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
                 const int n = n0 + wn * (BNO / 2) + i * 16 + fg * 4 + r;
                 if (n < a.N && k < a.K) {
                     float* p = &a.dw[(int64_t)n * a.lddw + k];
-                    if (single) *p += acc[i][j][r];
-                    else atomicAdd(p, acc[i][j][r]);
+                    if (gridDim.y == 1) *p += acc[i][j][r];          // single split: sole contributor
+                    else atomicAdd(p, acc[i][j][r]);                 // small outputs (64x64 tiles): few bytes, direct atomics
                 }
             }
         }
 }
 
+// dw[n][k] += sum_s slab[s][k][n]: 32x32 tiles, coalesced reads along n, LDS transpose, coalesced writes along k
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int Np, int Kp, float* dw, int N, int K, int lddw) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < splits; ++s) {
+        const float* sl = slab + (size_t)s * Kp * Np;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] += sl[(size_t)(k0 + ty + 8 * i) * Np + n0 + tx];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = acc[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + ty + 8 * i, k = k0 + tx;
+        if (n < N && k < K) dw[(int64_t)n * lddw + k] += tile[tx][ty + 8 * i];
+    }
+}
+
+// Splits over the reduction (pixel) axis: enough workgroups for ~3 per CU, every split >= 4 steps
+// (256 rows) deep, and the partial slabs (tiles x splits x tile elements) capped at 6 M floats
+// (24 MB: ~4 us to store, ~5 us to read back).
+static int tn_splits(int M, int N, int K, int bno, int bko, int* per_out) {
+    const int tiles = cdiv(N, bno) * cdiv(K, bko);
+    const long long out_elems = (long long)cdiv(N, bno) * bno * cdiv(K, bko) * bko;
+    long long by_ws = (6ll << 20) / (out_elems > 0 ? out_elems : 1);
+    if (by_ws < 1) by_ws = 1;
+    int want = cdiv(768, tiles);
+    int max_splits = cdiv(M, 256);
+    if (max_splits > by_ws) max_splits = (int)by_ws;
+    int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
+    int per = cdiv(M, splits);
+    per = (per + 63) / 64 * 64;
+    *per_out = per;
+    return cdiv(M, per);
+}
+static void tn_tile(int N, int K, int dtype, int* bno, int* bko) {
+    const bool big = dtype == CAPMI_BF16 && N >= 128 && K >= 128;
+    *bno = *bko = big ? 128 : 64;
+}
+
+extern "C" long long capmi_igemm_tn_ws_bytes(int M, int N, int K, int dtype) {
+    int bno, bko, per;
+    tn_tile(N, K, dtype, &bno, &bko);
+    const int splits = tn_splits(M, N, K, bno, bko, &per);
+    if (splits <= 1 || splits > 24 || bno < 128) return 0;
+    return (long long)splits * cdiv(N, bno) * bno * cdiv(K, bko) * bko * 4;
+}
+
 template <typename T, int BNO, int BKO>
-static int launch_tn(WGradArgs& a, hipStream_t st) {
+static int launch_tn(WGradArgs& a, float* ws, long long ws_bytes, hipStream_t st) {
     int tiles = cdiv(a.N, BNO) * cdiv(a.K, BKO);
     if (tiles <= 0 || a.M <= 0) return 0;
-    // Splits over the reduction (pixel) axis.  Every split adds its whole output tile with f32
-    // atomics, which the chip retires at only ~1.3 TB/s: cap the total atomic traffic
-    // (tiles x splits x tile bytes) at ~24 MB (~20 us) and keep every split >= 8 steps (256 rows)
-    // deep; within that, enough workgroups for ~3 per CU.
-    const long long out_elems = (long long)cdiv(a.N, BNO) * BNO * cdiv(a.K, BKO) * BKO;
-    long long by_atomics = (6ll << 20) / (out_elems > 0 ? out_elems : 1);
-    if (by_atomics < 1) by_atomics = 1;
-    int want = cdiv(768, tiles);
-    int max_splits = cdiv(a.M, 256);
-    if (max_splits > by_atomics) max_splits = (int)by_atomics;
-    int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
-    int per = cdiv(a.M, splits);
-    per = (per + 63) / 64 * 64;
-    splits = cdiv(a.M, per);
+    int per;
+    const int splits = tn_splits(a.M, a.N, a.K, BNO, BKO, &per);
     a.m_per_split = per;
+    a.Np = cdiv(a.N, BNO) * BNO;
+    a.Kp = cdiv(a.K, BKO) * BKO;
+    a.slab = nullptr;
+    const bool use_slab = splits > 1 && splits <= 24 && BNO >= 128;   // many splits / tiny outputs: the slab reduce would be latency-bound
+    if (use_slab) {
+        CAPMI_CHECK(ws && ws_bytes >= (long long)splits * a.Np * a.Kp * 4, "capmi_igemm_tn_wgrad: workspace too small (%lld bytes needed)",
+                    (long long)splits * a.Np * a.Kp * 4);
+        a.slab = ws;
+    }
     hipLaunchKernelGGL((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles, splits), dim3(256), 0, st, a);
+    if (use_slab)
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.Np / 32, a.Kp / 32), dim3(256), 0, st, ws, splits, a.Np, a.Kp, a.dw, a.N, a.K, a.lddw);
     CAPMI_LAUNCH_CHECK("capmi_igemm_tn_wgrad");
     return 0;
 }
 
 extern "C" int capmi_igemm_tn_wgrad(const void* x, const void* dy, float* dw, const capmi_conv_geom* g,
-                                    int N, int ldy, int lddw, int dtype, void* stream) {
+                                    int N, int ldy, int lddw, float* ws, long long ws_bytes, int dtype, void* stream) {
     CAPMI_CHECK(x && dy && dw && g, "capmi_igemm_tn_wgrad: null pointer");
     const int vec = dtype == CAPMI_F32 ? 4 : 8;
     CAPMI_CHECK(g->Cin % vec == 0 && g->ldx % vec == 0 && ldy % vec == 0,
@@ -881,12 +1067,13 @@ extern "C" int capmi_igemm_tn_wgrad(const void* x, const void* dy, float* dw, co
     a.fd_hw = fast_div(g->Ho * g->Wo); a.fd_w = fast_div(g->Wo);
     a.linear = (g->kh == 1 && g->kw == 1 && g->sd == 1 && g->up == 1 && g->pad == 0 && g->Hi == g->Ho && g->Wi == g->Wo) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
-    const bool big = N >= 128 && a.K >= 128;
+    int bno, bko;
+    tn_tile(N, a.K, dtype, &bno, &bko);
     if (dtype == CAPMI_BF16) {
-        if (big) return launch_tn<bf16, 128, 128>(a, st);
-        return launch_tn<bf16, 64, 64>(a, st);
+        if (bno == 128) return launch_tn<bf16, 128, 128>(a, ws, ws_bytes, st);
+        return launch_tn<bf16, 64, 64>(a, ws, ws_bytes, st);
     } else if (dtype == CAPMI_F32) {
-        return launch_tn<float, 64, 64>(a, st);
+        return launch_tn<float, 64, 64>(a, ws, ws_bytes, st);
     }
     capmi_set_error("capmi_igemm_tn_wgrad: bad dtype %d", dtype);
     return 1;

@@ -14,7 +14,7 @@ and the pointwise cell remain.  BPTT mirrors it.
 """
 import torch
 
-from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, Plan, gemm_geom
+from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, WGRAD_WS_BYTES, Plan, gemm_geom, wgrad_workspace
 from .params import FC
 
 
@@ -80,7 +80,8 @@ class DecoderRunner:
     def _wgrad(self, plan, x, rows, K, dy, N, dw, ldx=None, ldy=None, lddw=None):
         """dw[N][K] += dy[rows][N]^T . x[rows][K]"""
         g = gemm_geom(rows, K, ldx)
-        plan.add('capmi_igemm_tn_wgrad', x, dy, dw, g, N, N if ldy is None else ldy, K if lddw is None else lddw, self.code)
+        plan.add('capmi_igemm_tn_wgrad', x, dy, dw, g, N, N if ldy is None else ldy, K if lddw is None else lddw,
+                 _p(wgrad_workspace(self.store.device)), WGRAD_WS_BYTES, self.code)
 
     def _colsum(self, plan, a, rows, N, out, lda=None):
         plan.add('capmi_colsum', a, rows, N, N if lda is None else lda, out, self.code)

@@ -13,7 +13,7 @@ weight-gradient GEMM (split over pixels, f32 atomics) -> data-gradient GEMM.
 import torch
 
 from . import arch
-from ._lib import ACT_CODES, ConvGeom, Plan, gemm_geom, lib
+from ._lib import ACT_CODES, WGRAD_WS_BYTES, ConvGeom, Plan, gemm_geom, lib, wgrad_workspace
 from .params import stem_kpad
 
 BN_MOMENTUM = 0.9      # fluid.layers.batch_norm defaults; MobileNetV2.py:112-117 overrides neither
@@ -243,7 +243,7 @@ class EncoderRunner:
                 dwt = st.gview(op.name + '_weights')
                 if op.src == 0:
                     g = gemm_geom(M, self.kpad)
-                    plan.add('capmi_igemm_tn_wgrad', _p(self.col), _p(self.draw), _p(dwt), g, c, c, self.kpad, code)
+                    plan.add('capmi_igemm_tn_wgrad', _p(self.col), _p(self.draw), _p(dwt), g, c, c, self.kpad, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code)
                 elif op.groups > 1:
                     hi, wi, _ = self.shape[op.src]
                     plan.add('capmi_dwconv3x3_bwd_weight', _p(self.act[op.src]), _p(self.draw), _p(dwt), B, hi, wi, c, op.stride, ho, wo, code)
@@ -254,7 +254,7 @@ class EncoderRunner:
                 else:
                     g = self._conv_geom(op)
                     K = op.k * op.k * op.cin
-                    plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(self.draw), _p(dwt), g, c, c, K, code)
+                    plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(self.draw), _p(dwt), g, c, c, K, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code)
                     dx = self.grad[op.src]
                     acc = op.src in written
                     if op.stride == 1:

@@ -30,7 +30,7 @@ def _nt_tile(M, N, K, bf16):
     wide = N > 64
     if bf16:
         if wide:
-            big = K >= 512 and cd(M, 128) * cd(N, 128) >= 512
+            big = K >= 512 and cd(M, 128) * cd(N, 128) >= 384
             return (128 if big else 64, 128)
         return (128 if cd(M, 128) >= 512 else 64, 64)
     tall = cd(M, 128) * cd(N, 64) >= 256
@@ -54,10 +54,12 @@ def describe(name, args):
             nbytes += M * N * es
         if args[10]:
             nbytes += M * N * es
+        if code == BF16 and (bm, bn) == (128, 128):
+            return 'igemm_nt_glds_kernel', 2.0 * M * N * K, nbytes
         return 'igemm_nt_kernel<%s,%d,%d>' % ('bf16' if code == BF16 else 'f32', bm, bn), 2.0 * M * N * K, nbytes
     if name == 'capmi_igemm_tn_wgrad':
         g = _geom(args[3])
-        N, code = args[4], args[7]
+        N, code = args[4], args[9]
         M, K = g.B * g.Ho * g.Wo, g.kh * g.kw * g.Cin
         es = 2 if code == BF16 else 4
         big = N >= 128 and K >= 128 and code == BF16

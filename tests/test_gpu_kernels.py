@@ -62,7 +62,8 @@ def check(got, want, dtype, scale=None, name=''):
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (200, 72, 40), (130, 136, 104), (1216, 1000, 64), (37, 8, 16), (300, 260, 512),
-                                   (64, 2048, 512), (64, 512, 2048), (37, 50, 256), (4, 136, 384)])
+                                   (64, 2048, 512), (64, 512, 2048), (37, 50, 256), (4, 136, 384),
+                                   (24600, 260, 520), (49152, 136, 512)])     # the last two run the LDS-DMA pipeline kernel (bf16)
 def test_gemm_nt_epilogues(dtype, M, N, K):
     _lib, tdt, code = _env()
     rng = np.random.RandomState(M + N + K)
@@ -108,7 +109,8 @@ def _nhwc(x):
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('B,C,H,W,Co,k,s,pad', [(2, 16, 9, 9, 24, 3, 1, 1), (3, 8, 12, 10, 40, 3, 2, 1), (2, 32, 8, 8, 16, 1, 1, 0),
-                                                (2, 16, 8, 8, 32, 1, 2, 0), (1, 64, 14, 14, 64, 3, 1, 1)])
+                                                (2, 16, 8, 8, 32, 1, 2, 0), (1, 64, 14, 14, 64, 3, 1, 1),
+                                                (48, 64, 33, 31, 136, 3, 1, 1), (64, 64, 57, 57, 128, 3, 2, 1)])   # LDS-DMA pipeline kernel (bf16)
 def test_conv_fwd_dgrad_wgrad(dtype, B, C, H, W, Co, k, s, pad):
     _lib, tdt, code = _env()
     rng = np.random.RandomState(B * C + Co + k + s)
@@ -127,7 +129,7 @@ def test_conv_fwd_dgrad_wgrad(dtype, B, C, H, W, Co, k, s, pad):
     # weight gradient
     DY = dev(_nhwc(dy), tdt[dtype])
     DW = torch.zeros((Co, k, k, C), dtype=torch.float32, device=DEV)
-    _lib.call('capmi_igemm_tn_wgrad', p(X), p(DY), p(DW), g, Co, Co, k * k * C, code[dtype], stream())
+    _lib.call('capmi_igemm_tn_wgrad', p(X), p(DY), p(DW), g, Co, Co, k * k * C, p(_lib.wgrad_workspace(DEV)), _lib.WGRAD_WS_BYTES, code[dtype], stream())
     check(host(DW), dw.transpose(0, 2, 3, 1), dtype, name='conv wgrad')
     # data gradient through the flipped/transposed weight form
     WT = torch.zeros((C, k, k, Co), dtype=tdt[dtype], device=DEV)
@@ -184,7 +186,7 @@ def test_fc_wgrad_and_colsum(dtype, M, N, K):
     dy[:, :N] = rnd(rng.standard_normal((M, N)), dtype)
     X, DY = dev(x, tdt[dtype]), dev(dy, tdt[dtype])
     DW = torch.zeros((N, K), dtype=torch.float32, device=DEV)
-    _lib.call('capmi_igemm_tn_wgrad', p(X), p(DY), p(DW), _lib.gemm_geom(M, K), N, ldy, K, code[dtype], stream())
+    _lib.call('capmi_igemm_tn_wgrad', p(X), p(DY), p(DW), _lib.gemm_geom(M, K), N, ldy, K, p(_lib.wgrad_workspace(DEV)), _lib.WGRAD_WS_BYTES, code[dtype], stream())
     want = dy[:, :N].T @ x
     check(host(DW), want, dtype, name='fc wgrad')
     DB = torch.zeros(N, dtype=torch.float32, device=DEV)

@@ -68,7 +68,8 @@ for name, h, w, cin, cout, k, s, pad, ho, wo in rows:
     gd = _lib.ConvGeom(B, ho, wo, cout, h, w, k, k, 1, s, k - 1 - pad, cout)
     f = lambda st: _lib.lib().capmi_igemm_nt(p(x), p(wt), p(y), g, cout, K, cout, None, None, 0, None, 0, p(ws), 0, 0, 0, code, st)
     d = lambda st: _lib.lib().capmi_igemm_nt(p(y), p(wtT), p(dx), gd, cin, k * k * cout, cin, None, None, 0, None, 0, None, 0, 0, 0, code, st)
-    wg = lambda st: _lib.lib().capmi_igemm_tn_wgrad(p(x), p(y), p(dw), g, cout, cout, K, code, st)
+    wsb = _lib.wgrad_workspace(dev)
+    wg = lambda st: _lib.lib().capmi_igemm_tn_wgrad(p(x), p(y), p(dw), g, cout, cout, K, p(wsb), _lib.WGRAD_WS_BYTES, code, st)
     tf, td, tw = timeit(f), timeit(d), timeit(wg)
     fl = 2.0 * M * cout * K
     by = (B * h * w * cin + M * cout) * 2
