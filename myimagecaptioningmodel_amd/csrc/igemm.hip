@@ -526,12 +526,15 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
 // __syncthreads() in the loop (it would drain the DMA queue).
 __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
+template <int BM>
 __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(IGemmArgs a) {
     typedef bf16 T;
-    constexpr int BM = 128, BN = 128, BK = 32, NST = 4, WMW = 4;
-    constexpr int TM = 2, TN = 8;                       // 4x1 waves: 32 rows x 128 columns each
-    constexpr int OPB = BM * BK * 2;                    // bytes of one operand tile (8 KiB)
-    constexpr int STB = 2 * OPB;                        // bytes per stage
+    constexpr int BN = 128, BK = 32, NST = 4, WMW = 4;
+    constexpr int TM = BM / 64, TN = 8;                 // 4x1 waves: BM/4 rows x 128 columns each
+    constexpr int AOPB = BM * BK * 2, BOPB = BN * BK * 2;   // bytes of the A / B operand tiles
+    constexpr int STB = AOPB + BOPB;                    // bytes per stage (16 KiB / 12 KiB)
+    constexpr int ACNT = BM / 64, BCNT = 2;             // DMA instructions per thread per stage
+    constexpr int NGL = ACNT + BCNT;
     __shared__ __attribute__((aligned(1024))) char smem[NST * STB];
 
     const T* __restrict__ X = (const T*)a.x;
@@ -542,16 +545,17 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(IGemmArgs a) {
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
 
-    // this thread's two DMA slots per operand tile: rows (tid>>2) and 64 + (tid>>2), LDS chunk position
-    // tid&3, i.e. global chunk (tid&3) ^ ((tid>>4)&3) of that row ((row>>2)&3 is the same for both rows)
+    // this thread's DMA slots: rows (tid>>2) [+64], LDS chunk position tid&3, i.e. global chunk
+    // (tid&3) ^ ((tid>>4)&3) of that row ((row>>2)&3 is the same for row and row+64)
     const int chunk = (tid & 3) ^ ((tid >> 4) & 3);
-    RowPos rp[2];
-    const T* wrow[2];
-    bool wok[2];
+    RowPos rp[ACNT];
+    const T* wrow[BCNT];
+    bool wok[BCNT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < ACNT; ++i) rp[i] = row_pos(m0 + i * 64 + (tid >> 2), a.M, a.g, a.fd_hw, a.fd_w);
+#pragma unroll
+    for (int i = 0; i < BCNT; ++i) {
         const int l = i * 64 + (tid >> 2);
-        rp[i] = row_pos(m0 + l, a.M, a.g, a.fd_hw, a.fd_w);
         const int n = n0 + 8 * (l & 15) + (l >> 4);     // LDS row j*16+fr holds weight column TN*fr + j
         wok[i] = n < a.N;
         wrow[i] = W + (int64_t)(wok[i] ? n : 0) * a.ldw;
@@ -562,17 +566,17 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(IGemmArgs a) {
     auto issue_stage = [&](int st) {    // DMA of the tile at the current kp into ring slot st; advances kp
         char* base = smem + st * STB + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < ACNT; ++i) {
             const int64_t off = a_offset(rp[i], kp, a.K, a.g);
             const T* src = off >= 0 ? X + off : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < BCNT; ++i) {
             const T* src = (wok[i] && kp.k < a.K) ? wrow[i] + kp.k : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(base + OPB + i * 4096), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(base + AOPB + i * 4096), 16, 0, 0);
         }
         k_advance(kp, BK, a.g);
     };
@@ -585,24 +589,26 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(IGemmArgs a) {
 
     const int nkt = (a.K + BK - 1) / BK;
     const int fr = lane & 15, fg = lane >> 4;
-    // fragment byte offsets inside an operand tile (swizzled chunk position)
+    // fragment byte offsets inside a stage (swizzled chunk position)
     int aoff[TM], boff[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int row = wave * 32 + i * 16 + fr;
+        const int row = wave * (BM / 4) + i * 16 + fr;
         aoff[i] = row * 64 + ((fg ^ ((row >> 2) & 3)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int row = j * 16 + fr;
-        boff[j] = OPB + row * 64 + ((fg ^ ((row >> 2) & 3)) << 4);
+        boff[j] = AOPB + row * 64 + ((fg ^ ((row >> 2) & 3)) << 4);
     }
 
     issue_stage(0);
     issue_stage(1);
     issue_stage(2);
     for (int kt = 0; kt < nkt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // this thread's part of stage kt has landed
+        // this thread's part of stage kt has landed (the 2*NGL younger DMAs may still be in flight)
+        if constexpr (NGL == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // ... and everyone else's; all waves left stage kt-1
         asm volatile("" ::: "memory");
         issue_stage((kt + 3) & 3);                           // refill the slot that was read in iteration kt-1
@@ -815,13 +821,14 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
     }
     const NtCfg c = nt_cfg(a.M, N, a.K, dtype);
     if (dtype == CAPMI_BF16) {
-        if (c.bm == 128 && c.bn == 128) {
-            const int64_t tiles = (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128);
-            hipLaunchKernelGGL(igemm_nt_glds_kernel, dim3((unsigned)tiles), dim3(256), 0, st, a);
+        if (c.bn == 128) {      // LDS-DMA pipeline kernels
+            const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(a.N, 128);
+            CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
+            if (c.bm == 128) hipLaunchKernelGGL(igemm_nt_glds_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(igemm_nt_glds_kernel<64>, dim3((unsigned)tiles), dim3(256), 0, st, a);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
             return 0;
         }
-        if (c.bm == 64 && c.bn == 128) return launch_nt<bf16, 64, 128, 4>(a, st);
         if (c.bm == 128 && c.bn == 64) return launch_nt<bf16, 128, 64, 4>(a, st);
         return launch_nt<bf16, 64, 64, 4>(a, st);
     } else if (dtype == CAPMI_F32) {

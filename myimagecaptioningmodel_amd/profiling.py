@@ -54,8 +54,8 @@ def describe(name, args):
             nbytes += M * N * es
         if args[10]:
             nbytes += M * N * es
-        if code == BF16 and (bm, bn) == (128, 128):
-            return 'igemm_nt_glds_kernel', 2.0 * M * N * K, nbytes
+        if code == BF16 and bn == 128:
+            return 'igemm_nt_glds_kernel<%d>' % bm, 2.0 * M * N * K, nbytes
         return 'igemm_nt_kernel<%s,%d,%d>' % ('bf16' if code == BF16 else 'f32', bm, bn), 2.0 * M * N * K, nbytes
     if name == 'capmi_igemm_tn_wgrad':
         g = _geom(args[3])
