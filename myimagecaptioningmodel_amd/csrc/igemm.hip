@@ -847,7 +847,7 @@ struct WGradArgs {
     float* dw;
     int M, N, K;
     int ldy, lddw;
-    int m_per_split;
+    int m_per_split, splits;
     int linear;       // 1x1 / stride 1 / no padding: A(m,k) = x[m*ldx + k]
     float* slab;      // [splits][Kp][Np] f32 partial tiles (transposed), or NULL: add straight into dw
     int Np, Kp;
@@ -889,10 +889,15 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
     const T* __restrict__ DY = (const T*)a.dy;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
+    // split-major work order, dealt to the XCDs in contiguous runs: the tiles of one split (same pixel
+    // rows of dY and X) meet in one L2 instead of being fetched by all eight
     const int tiles_k = (a.K + BKO - 1) / BKO;
-    const int n0 = (blockIdx.x / tiles_k) * BNO;
-    const int k0 = (blockIdx.x % tiles_k) * BKO;
-    const int m_begin = blockIdx.y * a.m_per_split;
+    const int tiles = tiles_k * ((a.N + BNO - 1) / BNO);
+    const int id = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int split = id / tiles, tl = id - split * tiles;
+    const int n0 = (tl / tiles_k) * BNO;
+    const int k0 = (tl % tiles_k) * BKO;
+    const int m_begin = split * a.m_per_split;
     const int m_end = min(a.M, m_begin + a.m_per_split);
     if (m_begin >= m_end) return;
 
@@ -957,7 +962,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
     if (a.slab) {
         // partial tile -> slab[split][k][n] (transposed): the accumulator quad of a lane is 4
         // consecutive n of one k, i.e. one 16-byte store; no atomics (wgrad_reduce_kernel sums the splits)
-        float* sl = a.slab + (size_t)blockIdx.y * a.Kp * a.Np;
+        float* sl = a.slab + (size_t)split * a.Kp * a.Np;
 #pragma unroll
         for (int i = 0; i < TN_; ++i)
 #pragma unroll
@@ -978,7 +983,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
                 const int n = n0 + wn * (BNO / 2) + i * 16 + fg * 4 + r;
                 if (n < a.N && k < a.K) {
                     float* p = &a.dw[(int64_t)n * a.lddw + k];
-                    if (gridDim.y == 1) *p += acc[i][j][r];          // single split: sole contributor
+                    if (a.splits == 1) *p += acc[i][j][r];          // single split: sole contributor
                     else atomicAdd(p, acc[i][j][r]);                 // small outputs (64x64 tiles): few bytes, direct atomics
                 }
             }
@@ -1043,6 +1048,8 @@ static int launch_tn(WGradArgs& a, float* ws, long long ws_bytes, hipStream_t st
     int per;
     const int splits = tn_splits(a.M, a.N, a.K, BNO, BKO, &per);
     a.m_per_split = per;
+    a.splits = splits;
+    CAPMI_CHECK((long long)tiles * splits < (1ll << 31), "capmi_igemm_tn_wgrad: grid too large");
     a.Np = cdiv(a.N, BNO) * BNO;
     a.Kp = cdiv(a.K, BKO) * BKO;
     a.slab = nullptr;
@@ -1052,7 +1059,7 @@ static int launch_tn(WGradArgs& a, float* ws, long long ws_bytes, hipStream_t st
                     (long long)splits * a.Np * a.Kp * 4);
         a.slab = ws;
     }
-    hipLaunchKernelGGL((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles, splits), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles * splits), dim3(256), 0, st, a);
     if (use_slab)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.Np / 32, a.Kp / 32), dim3(256), 0, st, ws, splits, a.Np, a.Kp, a.dw, a.N, a.K, a.lddw);
     CAPMI_LAUNCH_CHECK("capmi_igemm_tn_wgrad");

@@ -78,31 +78,42 @@ extern "C" int capmi_weight_dgrad_form(const float* w, void* wt, int N, int kh, 
 }
 
 // All data-gradient weight forms of a model in ONE launch: a job table in device memory, one job per
-// (weight, 64K-element slice); blocks pick their job by index.
+// (weight, run of 16 tiles); a tile is 64 output channels x 64 input channels of one tap, transposed
+// through LDS so that both the f32 reads (along c) and the low-precision writes (along n) are coalesced.
 struct DgradJob {
     long long src_off, dst_off;     // element offsets into the f32 master / the shadow buffer
     int N, kh, kw, C, ldt;
-    int first;                      // first output element of this slice
+    int first;                      // first tile of this job; tile = (tap * ctiles + ct) * ntiles + nt
     int okh, okw;                   // taps of the OUTPUT form
     signed char rmap[4], qmap[4];   // output tap -> source tap
 };
 template <typename T>
 __global__ __launch_bounds__(256) void dgrad_form_batched_kernel(const float* __restrict__ flat, T* shadow, const DgradJob* __restrict__ jobs) {
+    __shared__ float tile[64][65];
     const DgradJob j = jobs[blockIdx.x];
-    const long long total = (long long)j.C * j.okh * j.okw * j.ldt;
+    const int ntiles = (j.ldt + 63) / 64, ctiles = (j.C + 63) / 64;
+    const int total = j.okh * j.okw * ctiles * ntiles;
     const float* w = flat + j.src_off;
     T* wt = shadow + j.dst_off;
-    for (int e = threadIdx.x; e < 65536; e += 256) {
-        long long i = (long long)j.first + e;
-        if (i >= total) break;
-        int n = (int)(i % j.ldt);
-        long long rest = i / j.ldt;
-        int q = (int)(rest % j.okw);
-        int r = (int)((rest / j.okw) % j.okh);
-        int c = (int)(rest / ((long long)j.okw * j.okh));
-        float f = 0.f;
-        if (n < j.N) f = w[(((long long)n * j.kh + j.rmap[r]) * j.kw + j.qmap[q]) * j.C + c];
-        wt[i] = from_f32<T>(f);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int last = min(total, j.first + 16);
+    for (int t = j.first; t < last; ++t) {
+        const int nt = t % ntiles, ct = (t / ntiles) % ctiles, tap = t / (ntiles * ctiles);
+        const int q = tap % j.okw, r = tap / j.okw;
+        const int n0 = nt * 64, c0 = ct * 64;
+        const long long tap_off = ((long long)j.rmap[r] * j.kw + j.qmap[q]) * j.C;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int n = n0 + ty + 4 * i, c = c0 + tx;
+            tile[ty + 4 * i][tx] = (n < j.N && c < j.C) ? w[(long long)n * j.kh * j.kw * j.C + tap_off + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + ty + 4 * i, n = n0 + tx;
+            if (c < j.C && n < j.ldt) wt[(((long long)c * j.okh + r) * j.okw + q) * j.ldt + n] = from_f32<T>(tile[tx][ty + 4 * i]);
+        }
+        __syncthreads();
     }
 }
 extern "C" int capmi_weight_dgrad_form_batched(const float* flat, void* shadow, const void* jobs, int njobs, int dtype, void* stream) {

@@ -201,3 +201,27 @@ def test_reference_shaped_facade_and_errors():
     assert ids.dtype == np.float32 and ids.shape == (4, ecfg['infer_max_length'])
     with pytest.raises(ValueError):
         exe.run(feed={'image': image[:, :, :32]}, fetch_list=[cap_var])
+
+
+@pytest.mark.parametrize('encoder', ['resnet50', 'mobilenetv2'])
+def test_weight_shadows_are_exact_transposes(encoder):
+    """The one-launch shadow refresh (capmi_cast + capmi_weight_dgrad_form_batched) against NumPy:
+    wT[c][r'][q'][n] = W[n][rmap[r']][qmap[q']][c], bit-exact after the same f32 -> bf16 rounding."""
+    ocfg, ecfg = _cfgs(encoder, 'slots', 'bf16', H=48, E=40, V=77)
+    params, _, _ = _data(ocfg, 2, 5)
+    eng = _engine(ecfg, params)
+    eng.refresh_shadows()
+    torch.cuda.synchronize()
+    st = eng.store
+    checked = 0
+    for key, (off, (n, kh, kw, c, ldt), rmap, qmap) in eng.wT_entries.items():
+        name = key if isinstance(key, str) else key[0]
+        e = st.entries[name]
+        w = st.flat[e.offset:e.offset + n * kh * kw * c].view(n, kh, kw, c)
+        want = torch.zeros(c, len(rmap), len(qmap), ldt, dtype=torch.float32, device=w.device)
+        sel = w[:, list(rmap)][:, :, list(qmap)]                       # [n][r'][q'][c]
+        want[..., :n] = sel.permute(3, 1, 2, 0)
+        got = eng.wT[off:off + want.numel()].view_as(want)
+        assert torch.equal(got, want.to(got.dtype)), key
+        checked += 1
+    assert checked >= 20
