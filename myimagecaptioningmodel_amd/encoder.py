@@ -73,6 +73,7 @@ class EncoderRunner:
             srcs = (op.src,) if not isinstance(op, arch.Add) else (op.a, op.b)
             for s in srcs:
                 consumers[s] = consumers.get(s, 0) + 1
+        self._consumers = consumers
         producer = {op.dst: op for op in enc.ops}
         self.fused_add = {}     # conv dst tensor id -> Add op folded into it
         self.skipped = set()
@@ -211,33 +212,127 @@ class EncoderRunner:
                          B, hi, wi, c, ho, wo, code)
 
     # ------------------------------------------------------------------ backward plan
+    def _backward_order(self):
+        """Reversed op order, except that a projection shortcut (a ConvBN whose output only feeds a
+        fused add) runs its backward just BEFORE the conv that owns the add: its strided 1x1 data
+        gradient (which leaves pixels untouched) then is the first writer of the block input's
+        gradient and the dense 1x1 of branch2a the last one, which can apply the ReLU mask."""
+        producer = {op.dst: op for op in self.enc.ops}
+        order, early = [], set()
+        for op in reversed(self.enc.ops):
+            if id(op) in self.skipped or id(op) in early:
+                continue
+            fa = self.fused_add.get(op.dst) if isinstance(op, arch.ConvBN) else None
+            if fa is not None:
+                p = producer.get(fa.a)
+                if isinstance(p, arch.ConvBN) and p.act is None and p.dst not in self.fused_add and self._consumers.get(p.dst, 0) == 1:
+                    order.append(p)
+                    early.add(id(p))
+            order.append(op)
+        return order, early
+
     def plan_backward(self, plan, weights, weights_bwd, segments=None):
         """Expects d(loss)/d(encoder output) in self.out_grad().  weights(name) -> forward filter,
         weights_bwd(name) -> its data-gradient form.  `segments`, if given, is a list that receives (plan_index, param_name)
-        marks after each op's parameter gradients are final (used to place all-reduce buckets)."""
+        marks after each op's parameter gradients are final (used to place all-reduce buckets).
+
+        Gradient buffers hold d(loss)/d(PRE-activation) wherever the last writer is a dense data-gradient
+        GEMM ("premasked"): its epilogue applies the activation mask of the tensor it completes, so the
+        batch-norm backward kernels of the producer read two tensors instead of three, and the shortcut
+        gradient of a fused residual add is the block-output gradient itself -- never copied (`pending`)."""
         assert self.need_backward
         st, B, code = self.store, self.B, self.code
-        written = {self.out_id}
-        for op in reversed(self.enc.ops):
+        NONE = ACT_CODES[None]
+        producer = {op.dst: op for op in self.enc.ops}
+        tensor_act = {}                 # activation applied where the tensor is produced
+        for op in self.enc.ops:
             if id(op) in self.skipped:
                 continue
             if isinstance(op, arch.ConvBN):
+                fa = self.fused_add.get(op.dst)
+                tensor_act[fa.dst if fa else op.dst] = fa.act if fa else op.act
+            elif isinstance(op, arch.Add):
+                tensor_act[op.dst] = op.act
+        order, early = self._backward_order()
+        last_writer = {}
+        for op in order:
+            if isinstance(op, arch.Add):
+                last_writer[op.a] = last_writer[op.b] = op
+            elif op.src != 0:
+                last_writer[op.src] = op
+        written = {self.out_id}
+        premasked = set()
+        pending = {}                    # tensor -> buffer that holds its first gradient contribution (alias, not a copy)
+        n_out = self.grad[self.out_id].numel()
+        if tensor_act.get(self.out_id) is not None:     # the decoder hands over d/d(post-activation): mask it once, in place
+            plan.add('capmi_act_bwd', _p(self.grad[self.out_id]), _p(self.act[self.out_id]), _p(self.grad[self.out_id]), 0, n_out,
+                     ACT_CODES[tensor_act[self.out_id]], code)
+        premasked.add(self.out_id)
+
+        def materialize(t):
+            """First contribution of `t` is an alias and the next writer cannot take an addend: copy it."""
+            if t in pending:
+                buf = pending.pop(t)
+                plan.add('capmi_act_bwd', _p(buf), _p(buf), _p(self.grad[t]), 0, self.grad[t].numel(), NONE, code)
+                written.add(t)
+
+        canonical = [op for op in reversed(self.enc.ops) if id(op) not in self.skipped]
+        marks_due = list(canonical)
+        done = set()
+
+        def flush_marks():
+            while marks_due and id(marks_due[0]) in done:
+                op = marks_due.pop(0)
+                if segments is not None and isinstance(op, arch.ConvBN):
+                    segments.append((len(plan), op.name))
+
+        def grad_buf(t):
+            return self.grad[t] if t in written else pending[t]
+
+        def ensure_premasked(t):
+            """Make grad[t] the pre-activation gradient with one in-place pass (only where the last writer could not)."""
+            if t not in premasked and tensor_act.get(t) is not None:
+                materialize(t)
+                plan.add('capmi_act_bwd', _p(self.grad[t]), _p(self.act[t]), _p(self.grad[t]), 0, self.grad[t].numel(),
+                         ACT_CODES[tensor_act[t]], code)
+            premasked.add(t)
+
+        shortcut_done = set()           # outputs of projection shortcuts whose backward already ran on the aliased gradient
+        for pos, op in enumerate(order):
+            if isinstance(op, arch.ConvBN):
+                if id(op) in early:     # projection shortcut: its output gradient IS the (masked) block-output gradient
+                    nxt = order[pos + 1]
+                    blk_out = self.fused_add[nxt.dst].dst
+                    ensure_premasked(blk_out)
+                    pending[op.dst] = grad_buf(blk_out)
+                    premasked.add(op.dst)
+                    shortcut_done.add(op.dst)
                 ho, wo, c = self.shape[op.dst]
                 M = B * ho * wo
                 bn = self.bn[op.dst]
                 raw = self.raw[op.dst]
                 fa = self.fused_add.get(op.dst)
                 out_id = fa.dst if fa else op.dst
-                act = ACT_CODES[fa.act if fa else op.act]
-                dy, y = self.grad[out_id], self.act[out_id]
+                t_act = fa.act if fa else op.act
+                act = NONE if (out_id in premasked or t_act is None) else ACT_CODES[t_act]
+                dy = grad_buf(out_id)
+                y = self.act[out_id]
                 red = st.gview(op.name + '_bn_offset')        # [d offset | d scale] adjacent in the flat buffer
                 assert c % 8 == 0 and st.entries[op.name + '_bn_scale'].offset == st.entries[op.name + '_bn_offset'].offset + c
                 plan.add('capmi_bn_bwd_reduce', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']), _p(self.bwd_ws), _p(red), M, c, act, code)
                 dres, dres_acc = None, 0
-                if fa is not None and fa.a != 0:
-                    dres = self.grad[fa.a]
-                    dres_acc = 1 if fa.a in written else 0
-                    written.add(fa.a)
+                if fa is not None and fa.a in shortcut_done:
+                    pending.pop(fa.a, None)
+                elif fa is not None and fa.a != 0:
+                    if act == NONE and fa.a not in written and fa.a not in pending:
+                        pending[fa.a] = dy              # shortcut gradient == (masked) block-output gradient
+                        if tensor_act.get(fa.a) is None:
+                            premasked.add(fa.a)
+                    else:
+                        materialize(fa.a)
+                        dres = self.grad[fa.a]
+                        dres_acc = 1 if fa.a in written else 0
+                        written.add(fa.a)
                 plan.add('capmi_bn_bwd_apply', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
                          _p(st.view(op.name + '_bn_scale')), _p(red), _p(self.draw), 0, _p(dres), dres_acc, M, c, act, code)
                 dwt = st.gview(op.name + '_weights')
@@ -247,6 +342,7 @@ class EncoderRunner:
                 elif op.groups > 1:
                     hi, wi, _ = self.shape[op.src]
                     plan.add('capmi_dwconv3x3_bwd_weight', _p(self.act[op.src]), _p(self.draw), _p(dwt), B, hi, wi, c, op.stride, ho, wo, code)
+                    materialize(op.src)
                     acc = 1 if op.src in written else 0
                     plan.add('capmi_dwconv3x3_bwd_data', _p(self.draw), _p(weights(op.name + '_weights')), _p(self.grad[op.src]),
                              B, hi, wi, c, op.stride, ho, wo, acc, code)
@@ -255,22 +351,29 @@ class EncoderRunner:
                     g = self._conv_geom(op)
                     K = op.k * op.k * op.cin
                     plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(self.draw), _p(dwt), g, c, c, K, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code)
-                    dx = self.grad[op.src]
-                    acc = op.src in written
+                    t = op.src
+                    dx = self.grad[t]
+                    src_act = tensor_act.get(t)
+                    is_last = last_writer.get(t) is op
+                    classes = None if op.stride == 1 else dgrad_class_offsets(op.k, op.stride, op.pad)
+                    covered = classes is None or len(classes) == op.stride * op.stride
+                    if not covered:
+                        materialize(t)          # pixels outside the classes keep their earlier contribution
+                    addend = dx if t in written else pending.pop(t, None)
+                    mask = is_last and covered and src_act is not None
+                    ysaved, dact = (_p(self.act[t]), ACT_CODES[src_act]) if mask else (None, 0)
                     if op.stride == 1:
                         gd = self._dgrad_geom(op)
                         Kd = op.k * op.k * op.cout
                         plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd(op.name + '_weights')), _p(dx), gd, op.cin, Kd, op.cin,
-                                 None, _p(dx) if acc else None, op.cin, None, 0, None, 0, 0, 0, code)
+                                 None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code)
                     else:
                         # strided conv: one dense GEMM per output-parity class over the compact grid,
                         # rows scattered to pixels (s*i+ph, s*j+pw) -- no MFMA on structural zeros
                         hi, wi, _ = self.shape[op.src]
-                        classes = dgrad_class_offsets(op.k, op.stride, op.pad)
-                        covered = len(classes) == op.stride * op.stride
-                        if not covered and not acc:      # some pixels get no gradient: start from zero
+                        if not covered and addend is None:      # some pixels get no gradient: start from zero
                             plan.add('capmi_fill_f32', _p(dx), 0.0, dx.numel() * dx.element_size() // 4)
-                            acc = True
+                            addend = dx
                         for (ph, pw), (d0h, d0w, nkh, nkw) in classes.items():
                             hc, wc = (hi - ph + op.stride - 1) // op.stride, (wi - pw + op.stride - 1) // op.stride
                             # ho = i + d0h + r'  <=>  hn = i*1 - pad' + r' with pad' = -d0h
@@ -278,19 +381,24 @@ class EncoderRunner:
                             if d0h != d0w:
                                 raise NotImplementedError('asymmetric parity classes')
                             plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd((op.name + '_weights', ph, pw))), _p(dx), gd, op.cin,
-                                     nkh * nkw * op.cout, op.cin, None, _p(dx) if acc else None, op.cin, None, 0, None, 0, 0, 0, code)
-                    written.add(op.src)
-                if segments is not None:
-                    segments.append((len(plan), op.name))
+                                     nkh * nkw * op.cout, op.cin, None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code)
+                    written.add(t)
+                    if is_last and (mask or src_act is None):
+                        premasked.add(t)
             elif isinstance(op, arch.Add):
                 n = self.act[op.dst].numel()
+                act = NONE if (op.dst in premasked or op.act is None) else ACT_CODES[op.act]
+                src = self.grad[op.dst] if op.dst in written else pending[op.dst]
                 for t in (op.a, op.b):
-                    plan.add('capmi_act_bwd', _p(self.grad[op.dst]), _p(self.act[op.dst]), _p(self.grad[t]), 1 if t in written else 0,
-                             n, ACT_CODES[op.act], code)
+                    materialize(t)
+                    plan.add('capmi_act_bwd', _p(src), _p(self.act[op.dst]), _p(self.grad[t]), 1 if t in written else 0, n, act, code)
                     written.add(t)
             else:
                 hi, wi, c = self.shape[op.src]
                 ho, wo, _ = self.shape[op.dst]
-                assert op.src not in written
+                assert op.src not in written and op.src not in pending
+                materialize(op.dst)
                 plan.add('capmi_maxpool3x3s2_bwd', _p(self.grad[op.dst]), _p(self.pool_idx[op.dst]), _p(self.grad[op.src]), B, hi, wi, c, ho, wo, code)
                 written.add(op.src)
+            done.add(id(op))
+            flush_marks()
