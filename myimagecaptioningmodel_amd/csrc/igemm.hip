@@ -526,10 +526,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
 // __syncthreads() in the loop (it would drain the DMA queue).
 __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
-template <int BM>
-__global__ __launch_bounds__(256) void igemm_nt_glds_kernel(IGemmArgs a) {
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BM, int NST>
+__global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_kernel(IGemmArgs a) {
     typedef bf16 T;
-    constexpr int BN = 128, BK = 32, NST = 4, WMW = 4;
+    constexpr int BN = 128, BK = 32, WMW = 4;
     constexpr int TM = BM / 64, TN = 8;                 // 4x1 waves: BM/4 rows x 128 columns each
     constexpr int AOPB = BM * BK * 2, BOPB = BN * BK * 2;   // bytes of the A / B operand tiles
     constexpr int STB = AOPB + BOPB;                    // bytes per stage (16 KiB / 12 KiB)
@@ -602,17 +604,17 @@ __global__ __launch_bounds__(256) void igemm_nt_glds_kernel(IGemmArgs a) {
         boff[j] = AOPB + row * 64 + ((fg ^ ((row >> 2) & 3)) << 4);
     }
 
-    issue_stage(0);
-    issue_stage(1);
-    issue_stage(2);
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p) issue_stage(p);
+    int slot = 0;                                            // ring slot of stage kt
     for (int kt = 0; kt < nkt; ++kt) {
-        // this thread's part of stage kt has landed (the 2*NGL younger DMAs may still be in flight)
-        if constexpr (NGL == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // this thread's part of stage kt has landed (the (NST-2)*NGL younger DMAs may still be in flight)
+        wait_vmcnt<(NST - 2) * NGL>();
         __builtin_amdgcn_s_barrier();                        // ... and everyone else's; all waves left stage kt-1
         asm volatile("" ::: "memory");
-        issue_stage((kt + 3) & 3);                           // refill the slot that was read in iteration kt-1
-        const char* st = smem + (kt & 3) * STB;
+        issue_stage(slot == 0 ? NST - 1 : slot - 1);         // refill the slot that was read in iteration kt-1
+        const char* st = smem + slot * STB;
+        slot = slot + 1 == NST ? 0 : slot + 1;
         Frag<T> af[TM], bf[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i].load(reinterpret_cast<const T*>(st + aoff[i]));
@@ -824,8 +826,8 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
         if (c.bn == 128) {      // LDS-DMA pipeline kernels
             const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(a.N, 128);
             CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
-            if (c.bm == 128) hipLaunchKernelGGL(igemm_nt_glds_kernel<128>, dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL(igemm_nt_glds_kernel<64>, dim3((unsigned)tiles), dim3(256), 0, st, a);
+            if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
             return 0;
         }
