@@ -64,6 +64,24 @@ int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom*
                    const void* ysaved, int ld_saved, float* stats,
                    int act, int dact, int out_f32, int dtype, void* stream);
 
+/* Data-gradient GEMM whose OUTPUT completes the gradient of a batch-normalised tensor: capmi_igemm_nt
+ * (bias, act, statistics off; output dense, ldy == N) plus, in the same epilogue, the first stage of
+ * capmi_bn_bwd_reduce for the `nred` (1 or 2) layers that take this output as their dy (the layer
+ * that produced the tensor; a projection shortcut that shares the gradient).  Target q: rx_q = that
+ * layer's conv output [rows][N] (indexed like y, scattered rows included), its saved mean / invstd,
+ * and ws_q[part][2][N] f32: part p = rows [p*R, (p+1)*R) of this GEMM with
+ * R = capmi_igemm_nt_bnred_part_rows(g, N, dtype) (0: not available for this shape -- use
+ * capmi_bn_bwd_reduce); ws_q[p][0][n] = sum dz, ws_q[p][1][n] = sum dz*(x-mean)*invstd with dz the
+ * value stored to y.  Plain stores, one producer per element: deterministic.  Finish with
+ * capmi_bn_bwd_reduce_final.  Replaces one full read of dy and of the conv output per BN layer
+ * (fluid batch_norm_grad, model_adaAttention_aic.py:193-195 backward). */
+int capmi_igemm_nt_bnred_part_rows(const capmi_conv_geom* g, int N, int dtype);
+int capmi_igemm_nt_bnred(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                         const void* addend, int ld_addend, const void* ysaved, int ld_saved, int dact,
+                         int nred, const void* rx0, const float* mean0, const float* invstd0, float* ws0,
+                         const void* rx1, const float* mean1, const float* invstd1, float* ws1,
+                         int dtype, void* stream);
+
 /* dW[n][k] += sum_m dY[m][n] * A(m,k): weight gradient (f32 output; the caller zeroes dW once per
  * step).  The pixel axis is split over workgroups; each split stores its partial tile to the f32
  * workspace `ws` (capmi_igemm_tn_ws_bytes(M,N,K,dtype) bytes; 0 = not needed) and a second kernel
@@ -126,6 +144,9 @@ int capmi_bn_bwd_ws_floats(int M, int C, int dtype);
 int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y, const float* saved_mean,
                         const float* saved_invstd, float* ws, float* red, int M, int C, int act,
                         int dtype, void* stream);
+/* Second stage alone, for partial sums from capmi_igemm_nt_bnred: red[0..C) += sum_p ws[p][0][c],
+ * red[C..2C) += sum_p ws[p][1][c]. */
+int capmi_bn_bwd_reduce_final(const float* ws, int nparts, int C, float* red, void* stream);
 int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, const float* saved_mean,
                        const float* saved_invstd, const float* scale, const float* red,
                        void* dx, int dx_accumulate, void* dres, int dres_accumulate,

@@ -31,6 +31,7 @@ _g = ctypes.POINTER(ConvGeom)
 # name -> argument ctypes (the trailing `void* stream` included).  Must list every symbol of capmi.h.
 SIGNATURES = {
     'capmi_igemm_nt': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
+    'capmi_igemm_nt_bnred': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
     'capmi_colsum': [_p, _i, _i, _i, _p, _i, _p],
     'capmi_im2col_stem': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -43,6 +44,7 @@ SIGNATURES = {
     'capmi_bn_finalize': [_p, _i, _i, _i, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p],
     'capmi_bn_apply': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_reduce': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_bn_bwd_reduce_final': [_p, _i, _i, _p, _p],
     'capmi_bn_bwd_apply': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     'capmi_add_act': [_p, _p, _p, _l, _i, _i, _p],
     'capmi_act_bwd': [_p, _p, _p, _i, _l, _i, _i, _p],
@@ -78,6 +80,7 @@ class CapmiError(RuntimeError):
 # queries without a stream argument: name -> argument ctypes (return the part size, > 0)
 QUERIES = {
     'capmi_igemm_nt_stats_part_rows': [_i, _i, _i, _i],
+    'capmi_igemm_nt_bnred_part_rows': [_g, _i, _i],
     'capmi_bn_stats_part_rows': [_i, _i, _i],
     'capmi_bn_bwd_ws_floats': [_i, _i, _i],
 }

@@ -263,29 +263,42 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
 
 // one workgroup per 16 entries of the [2C] vector; 16 thread groups stride over the partial rows
 // with 8 independent loads in flight each (the partials are L2-resident: this is latency, not bytes)
-__global__ __launch_bounds__(256) void bn_bwd_reduce_final_kernel(const float* __restrict__ ws, int nblocks, int n2c, float* red) {
-    __shared__ float s[16][17];
+template <int LANES>      // 16 columns x LANES part lanes per block
+__global__ __launch_bounds__(16 * LANES) void bn_bwd_reduce_final_kernel(const float* __restrict__ ws, int nblocks, int n2c, float* red) {
+    __shared__ float s[LANES][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + tx;
     float acc = 0.f;
     if (j < n2c) {
         int b = ty;
-        for (; b + 7 * 16 < nblocks; b += 8 * 16) {
+        for (; b + 7 * LANES < nblocks; b += 8 * LANES) {
             float t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) t[u] = ws[(int64_t)(b + u * 16) * n2c + j];
+            for (int u = 0; u < 8; ++u) t[u] = ws[(int64_t)(b + u * LANES) * n2c + j];
             acc += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         }
-        for (; b < nblocks; b += 16) acc += ws[(int64_t)b * n2c + j];
+        for (; b < nblocks; b += LANES) acc += ws[(int64_t)b * n2c + j];
     }
     s[ty][tx] = acc;
     __syncthreads();
     if (ty == 0 && j < n2c) {
         float tot = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tot += s[r][tx];
+        for (int r = 0; r < LANES; ++r) tot += s[r][tx];
         red[j] += tot;
     }
+}
+static void launch_bwd_reduce_final(const float* ws, int nparts, int C, float* red, hipStream_t st) {
+    if (nparts > 512) hipLaunchKernelGGL(bn_bwd_reduce_final_kernel<64>, dim3(cdiv(2 * C, 16)), dim3(1024), 0, st, ws, nparts, 2 * C, red);
+    else hipLaunchKernelGGL(bn_bwd_reduce_final_kernel<16>, dim3(cdiv(2 * C, 16)), dim3(256), 0, st, ws, nparts, 2 * C, red);
+}
+/* Second stage alone: red[0..C) += sum_p ws[p][0][c], red[C..2C) += sum_p ws[p][1][c] -- for partial sums
+ * produced by capmi_igemm_nt_bnred's epilogue. */
+extern "C" int capmi_bn_bwd_reduce_final(const float* ws, int nparts, int C, float* red, void* stream) {
+    CAPMI_CHECK(ws && red && nparts > 0 && C > 0, "capmi_bn_bwd_reduce_final: bad arguments");
+    launch_bwd_reduce_final(ws, nparts, C, red, (hipStream_t)stream);
+    CAPMI_LAUNCH_CHECK("capmi_bn_bwd_reduce_final");
+    return 0;
 }
 
 static ColLayout bwd_reduce_layout(int M, int C, int vec, int* gx, int* gy) {
@@ -317,7 +330,7 @@ extern "C" int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y,
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)x,
                            (const T*)y, saved_mean, saved_invstd, ws, M, C, act, L);
     });
-    hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3(cdiv(2 * C, 16)), dim3(256), 0, (hipStream_t)stream, ws, gx, 2 * C, red);
+    launch_bwd_reduce_final(ws, gx, C, red, (hipStream_t)stream);
     CAPMI_LAUNCH_CHECK("capmi_bn_bwd_reduce");
     return 0;
 }

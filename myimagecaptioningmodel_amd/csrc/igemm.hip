@@ -37,6 +37,13 @@ struct IGemmArgs {
     capmi_conv_geom g;
     FastDiv fd_hw, fd_w;             // division by Ho*Wo and by Wo
     int act, dact, out_f32;
+    // fused batch-norm backward reduction (data-gradient launches): for each of `nred` layers that take
+    // this launch's OUTPUT as their dy, per-workgroup column sums of dz and dz*(x-mean)*invstd
+    int nred;
+    const void* rx[2];               // the layer's conv output [rows][N], same row indexing as y
+    const float* rmean[2];
+    const float* rinv[2];
+    float* rws[2];                   // [row block][2][N] partial sums
 #ifdef CAPMI_STAMPS
     unsigned long long* stamps;      // diagnostic build only: [workgroup][8] s_memtime stamps
 #endif
@@ -277,7 +284,7 @@ template <int TN> __device__ __forceinline__ void dact_run(float (&v)[TN], const
 }
 
 // ------------------------------------------------------------------ shared epilogue of the tiled NT kernels
-template <typename T, int BM, int BN, int WMW>
+template <typename T, int BM, int BN, int WMW, bool RED = false>
 __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred) {
     constexpr int WNW = 4 / WMW, RW = BM / WMW, WN = BN / WNW, TM = RW / 16, TN = WN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -354,37 +361,88 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
     }
     const T* addend = (const T*)a.addend;
     const T* ysaved = (const T*)a.ysaved;
-    const bool vec_ok = (a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N;
+    const bool vec_ok = (a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N &&
+                        (!a.nred || a.N % TN == 0);
+    typedef T __attribute__((ext_vector_type(TN))) RunT;      // TN consecutive values of one row, as loaded
+    // Fused batch-norm backward reduction (capmi_igemm_nt_bnred): this launch's output is the dy of up to
+    // two BN layers.  Target 0's sums are taken while the rows are stored; target 1 (rare) in a later pass.
+    const T* rx0 = (const T*)a.rx[0];
+    float mu0[TN], s1[TN], s2[TN];
+    if constexpr (RED) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const bool ok = col0 + j < a.N;
+            mu0[j] = ok ? a.rmean[0][col0 + j] : 0.f;
+            s1[j] = 0.f; s2[j] = 0.f;
+        }
+    }
     if (col0 < a.N) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            int64_t rows[4];
+            bool valid[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int rl = i * 16 + fg * 4 + r;
-                if (!rows_full && rl >= wcnt) continue;
+                valid[r] = rows_full || rl < wcnt;
                 int64_t row = wrow0 + rl;
-                if (a.g.os > 1) {          // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
+                if (a.g.os > 1 && valid[r]) {  // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
                     const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
                     const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
                     row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
                 }
-                float v[TN], t[TN];
+                rows[r] = row;
+            }
+            if (vec_ok) {
+                // all loads of the four rows first (the output may alias the addend, so the compiler cannot
+                // hoist a row's loads over the previous row's store by itself: one memory latency, not four)
+                constexpr int RB = RED ? 2 : 4;      // rows per load batch (register budget)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
-                if (vec_ok) {
+                for (int h = 0; h < 4; h += RB) {
+                RunT pa[4], py[4], px[4];
+#pragma unroll
+                for (int r = h; r < h + RB; ++r) {
+                    if (addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
+                    if (a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
+                    if (RED && valid[r]) px[r] = *reinterpret_cast<const RunT*>(rx0 + rows[r] * a.N + col0);
+                }
+#pragma unroll
+                for (int r = h; r < h + RB; ++r) {
+                    if (!valid[r]) continue;
+                    float v[TN], t[TN];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
                     if (addend) {
-                        load_run<T, TN>(addend + row * a.ld_addend + col0, t);
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) v[j] += t[j];
+                        for (int j = 0; j < TN; ++j) v[j] += (float)pa[r][j];
                     }
                     act_run<TN>(v, a.act);
                     if (a.dact) {
-                        load_run<T, TN>(ysaved + row * a.ld_saved + col0, t);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) t[j] = (float)py[r][j];
                         dact_run<TN>(v, t, a.dact);
                     }
-                    if (a.out_f32) store_run<float, TN>((float*)a.y + row * a.ldy + col0, v);
-                    else store_run<T, TN>((T*)a.y + row * a.ldy + col0, v);
-                } else {
+                    if (a.out_f32) store_run<float, TN>((float*)a.y + rows[r] * a.ldy + col0, v);
+                    else store_run<T, TN>((T*)a.y + rows[r] * a.ldy + col0, v);
+                    if constexpr (RED) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float dz = (a.out_f32 || sizeof(T) == 4) ? v[j] : to_f32(from_f32<T>(v[j]));   // the value the BN apply pass reads
+                            acc[i][j][r] = dz;
+                            s1[j] += dz;
+                            s2[j] += dz * ((float)px[r][j] - mu0[j]);      // * invstd when the part is written
+                        }
+                    }
+                }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!valid[r]) continue;
+                    const int64_t row = rows[r];
+                    float v[TN], t[TN];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
                     const int nv = min(TN, a.N - col0);
                     if (addend) {
 #pragma unroll
@@ -402,8 +460,75 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                             if (a.out_f32) ((float*)a.y)[row * a.ldy + col0 + j] = v[j];
                             else ((T*)a.y)[row * a.ldy + col0 + j] = from_f32<T>(v[j]);
                         }
+                    if constexpr (RED) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float dz = j < nv ? ((a.out_f32 || sizeof(T) == 4) ? v[j] : to_f32(from_f32<T>(v[j]))) : 0.f;
+                            acc[i][j][r] = dz;
+                            s1[j] += dz;
+                            if (j < nv) s2[j] += dz * (to_f32(rx0[row * a.N + col0 + j]) - mu0[j]);
+                        }
+                    }
                 }
             }
+        }
+    }
+    if constexpr (RED)
+    for (int q = 0; q < a.nred; ++q) {
+        if (q > 0) {        // second target: another pass over the stored values (acc holds them)
+            const T* rx = (const T*)a.rx[q];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const bool ok = col0 + j < a.N;
+                mu0[j] = ok ? a.rmean[q][col0 + j] : 0.f;
+                s1[j] = 0.f; s2[j] = 0.f;
+            }
+            if (col0 < a.N) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rl = i * 16 + fg * 4 + r;
+                        if (!rows_full && rl >= wcnt) continue;
+                        int64_t row = wrow0 + rl;
+                        if (a.g.os > 1) {
+                            const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
+                            const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
+                            row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
+                        }
+                        float t[TN];
+                        if (vec_ok) load_run<T, TN>(rx + row * a.N + col0, t);
+                        else {
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) t[j] = col0 + j < a.N ? to_f32(rx[row * a.N + col0 + j]) : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            s1[j] += acc[i][j][r];
+                            s2[j] += acc[i][j][r] * (t[j] - mu0[j]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float r1 = row4_sum(s1[j]), r2 = row4_sum(s2[j]);
+            if (fg == 0) {
+                const int c = wn * WN + TN * fr + j;
+                sred[(wm * BN + c) * 2 + 0] = r1;
+                sred[(wm * BN + c) * 2 + 1] = r2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.N && m0 < a.M) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) { t1 += sred[(w * BN + tid) * 2]; t2 += sred[(w * BN + tid) * 2 + 1]; }
+            float* w = a.rws[q] + (int64_t)(m0 / BM) * 2 * a.N + n0 + tid;
+            w[0] = t1;
+            w[a.N] = t2 * a.rinv[q][n0 + tid];
         }
     }
 }
@@ -414,7 +539,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 // fragment reads keep their conflict-free addresses).  Each lane then owns TN CONSECUTIVE output
 // columns of every row it holds: the epilogue stores straight from registers -- a wave instruction
 // writes 4 rows x (16 lanes x TN values) = whole 128-byte lines (bf16, TN = 4), no LDS round trip.
-template <typename T, int BM, int BN, int WMW>
+template <typename T, int BM, int BN, int WMW, bool RED = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
     // WMW x (4/WMW) waves.  BK = 64 with ONE LDS stage + one stage in registers: the next tile's 16-byte loads (8 per
     // thread for a 128x128 tile) are in flight during the whole compute phase.  The small-K convs
@@ -507,7 +632,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
     }
 
     STAMP(3);
-    nt_epilogue<T, BM, BN, WMW>(a, acc, m0, n0, reinterpret_cast<float*>(As));
+    nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(As));
     STAMP(5);
 #ifdef CAPMI_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -528,7 +653,7 @@ __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int NST>
+template <int BM, int NST, bool RED = false>
 __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_kernel(IGemmArgs a) {
     typedef bf16 T;
     constexpr int BN = 128, BK = 32, WMW = 4;
@@ -627,7 +752,7 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the (zero-page) tail stages before LDS reuse
     __syncthreads();
-    nt_epilogue<T, BM, BN, WMW>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
+    nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
 }
 
 // ------------------------------------------------------------------ skinny NT kernel (M <= 64)
@@ -782,15 +907,23 @@ static int launch_nt(const IGemmArgs& a, hipStream_t st) {
     int64_t tiles = (int64_t)cdiv(a.M, BM) * cdiv(a.N, BN);
     if (tiles <= 0) return 0;
     CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
-    hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WMW>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    if (a.nred) hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WMW, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WMW>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     CAPMI_LAUNCH_CHECK("capmi_igemm_nt");
     return 0;
 }
 
-extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom* g,
-                              int N, int ldw, int ldy, const float* bias, const void* addend,
-                              int ld_addend, const void* ysaved, int ld_saved, float* stats,
-                              int act, int dact, int out_f32, int dtype, void* stream) {
+struct BnRedTarget { const void* x; const float* mean; const float* invstd; float* ws; };
+
+static bool nt_uses_skinny(const capmi_conv_geom* g, int M, int K, bool stats, int dtype) {
+    const bool plain = g->kh == 1 && g->kw == 1 && g->sd == 1 && g->up == 1 && g->pad == 0 && g->Hi == 1 && g->Wi == 1 && g->Ho == 1 && g->Wo == 1;
+    return plain && g->os <= 1 && !stats && M <= 64 && K % 128 == 0 && K >= 256 && (dtype == CAPMI_BF16 || dtype == CAPMI_F32);
+}
+
+static int igemm_nt_impl(const void* x, const void* w, void* y, const capmi_conv_geom* g,
+                         int N, int ldw, int ldy, const float* bias, const void* addend,
+                         int ld_addend, const void* ysaved, int ld_saved, float* stats,
+                         int act, int dact, int out_f32, int nred, const BnRedTarget* red, int dtype, void* stream) {
     CAPMI_CHECK(x && w && y && g, "capmi_igemm_nt: null pointer");
     const int vec = dtype == CAPMI_F32 ? 4 : 8;
     CAPMI_CHECK(g->Cin % vec == 0 && g->ldx % vec == 0 && ldw % vec == 0,
@@ -806,6 +939,11 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldw = ldw; a.ldy = ldy; a.ld_addend = ld_addend; a.ld_saved = ld_saved;
     a.g = *g; a.act = act; a.dact = dact; a.out_f32 = out_f32;
+    a.nred = nred;
+    for (int q = 0; q < 2; ++q) {
+        a.rx[q] = q < nred ? red[q].x : nullptr; a.rmean[q] = q < nred ? red[q].mean : nullptr;
+        a.rinv[q] = q < nred ? red[q].invstd : nullptr; a.rws[q] = q < nred ? red[q].ws : nullptr;
+    }
     CAPMI_CHECK((long long)(a.M + 256) * g->Ho * g->Wo < (1ll << 40), "capmi_igemm_nt: M * Ho*Wo outside the fast-division range");
     a.fd_hw = fast_div(g->Ho * g->Wo); a.fd_w = fast_div(g->Wo);
 #ifdef CAPMI_STAMPS
@@ -813,8 +951,8 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
 #endif
     CAPMI_CHECK(ldw >= a.K, "capmi_igemm_nt: ldw=%d < K=%d", ldw, a.K);
     hipStream_t st = (hipStream_t)stream;
-    const bool plain = g->kh == 1 && g->kw == 1 && g->sd == 1 && g->up == 1 && g->pad == 0 && g->Hi == 1 && g->Wi == 1 && g->Ho == 1 && g->Wo == 1;
-    if (plain && g->os <= 1 && !stats && a.M <= 64 && a.K % 128 == 0 && a.K >= 256 && (dtype == CAPMI_BF16 || dtype == CAPMI_F32)) {
+    if (nt_uses_skinny(g, a.M, a.K, stats != nullptr, dtype)) {
+        CAPMI_CHECK(nred == 0, "capmi_igemm_nt_bnred: not available for M <= 64 plain products (see capmi_igemm_nt_bnred_part_rows)");
         // decoder recurrence and other M <= 64 products: skinny kernel (64x32 tiles, K split over waves)
         if (dtype == CAPMI_BF16) hipLaunchKernelGGL(igemm_nt_skinny_kernel<bf16>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);
         else hipLaunchKernelGGL(igemm_nt_skinny_kernel<float>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);
@@ -826,7 +964,9 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
         if (c.bn == 128) {      // LDS-DMA pipeline kernels
             const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(a.N, 128);
             CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
-            if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            if (c.bm == 128 && a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             else hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
             return 0;
@@ -840,6 +980,31 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
     }
     capmi_set_error("capmi_igemm_nt: bad dtype %d", dtype);
     return 1;
+}
+
+extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom* g,
+                              int N, int ldw, int ldy, const float* bias, const void* addend,
+                              int ld_addend, const void* ysaved, int ld_saved, float* stats,
+                              int act, int dact, int out_f32, int dtype, void* stream) {
+    return igemm_nt_impl(x, w, y, g, N, ldw, ldy, bias, addend, ld_addend, ysaved, ld_saved, stats, act, dact, out_f32, 0, nullptr, dtype, stream);
+}
+
+extern "C" int capmi_igemm_nt_bnred_part_rows(const capmi_conv_geom* g, int N, int dtype) {
+    if (!g) return 0;
+    const int M = g->B * g->Ho * g->Wo, K = g->kh * g->kw * g->Cin;
+    if (nt_uses_skinny(g, M, K, false, dtype)) return 0;
+    return nt_cfg(M, N, K, dtype).bm;
+}
+
+extern "C" int capmi_igemm_nt_bnred(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                                    const void* addend, int ld_addend, const void* ysaved, int ld_saved, int dact,
+                                    int nred, const void* rx0, const float* mean0, const float* invstd0, float* ws0,
+                                    const void* rx1, const float* mean1, const float* invstd1, float* ws1, int dtype, void* stream) {
+    CAPMI_CHECK(nred >= 1 && nred <= 2, "capmi_igemm_nt_bnred: nred=%d (1 or 2)", nred);
+    CAPMI_CHECK(rx0 && mean0 && invstd0 && ws0 && (nred < 2 || (rx1 && mean1 && invstd1 && ws1)), "capmi_igemm_nt_bnred: null reduction target");
+    CAPMI_CHECK(ldy == N, "capmi_igemm_nt_bnred: output must be dense (ldy == N)");
+    BnRedTarget red[2] = {{rx0, mean0, invstd0, ws0}, {rx1, mean1, invstd1, ws1}};
+    return igemm_nt_impl(x, w, y, g, N, ldw, ldy, nullptr, addend, ld_addend, ysaved, ld_saved, nullptr, 0, dact, 0, nred, red, dtype, stream);
 }
 
 // ------------------------------------------------------------------ TN kernel (weight gradient)

@@ -66,6 +66,7 @@ class EncoderRunner:
         self.code, self.tdt = dtype_code, torch_dtype
         self.dev = store.device
         self.need_backward = need_backward
+        self.fuse_bn_reduce = False     # BN backward sums from the dgrad epilogue (capmi_igemm_nt_bnred): measured slower than the streaming reduce
         enc = self.enc
         # ---- fold `add` ops into the bn_apply of the conv that produces their second operand
         consumers = {}
@@ -134,6 +135,10 @@ class EncoderRunner:
                 h, w, c = self.shape[op.dst]
                 ws = max(ws, lib().capmi_bn_bwd_ws_floats(B * h * w, c, dtype_code))
         self.bwd_ws = z((ws,), torch.float32) if need_backward else None  # partial sums of bn_bwd_reduce (scratch)
+        # partial sums written by data-gradient epilogues (capmi_igemm_nt_bnred): <= one part per 64 rows (+ class tails)
+        red_floats = max([(((B * self.shape[op.dst][0] * self.shape[op.dst][1] + 63) // 64) + 8) * 2 * self.shape[op.dst][2]
+                          for op in enc.ops if isinstance(op, arch.ConvBN)] or [0])
+        self.red_ws = [z((red_floats,), torch.float32), z((red_floats,), torch.float32)] if need_backward else None
         stem = enc.ops[0]
         h, w, _ = self.shape[stem.dst]
         self.kpad = stem_kpad(stem.k, stem.cin)
@@ -298,6 +303,26 @@ class EncoderRunner:
             premasked.add(t)
 
         shortcut_done = set()           # outputs of projection shortcuts whose backward already ran on the aliased gradient
+        conv_of_out = {}                # tensor id -> the ConvBN whose (fused-add) output it is
+        for o in self.enc.ops:
+            if isinstance(o, arch.ConvBN) and id(o) not in self.skipped:
+                f = self.fused_add.get(o.dst)
+                conv_of_out[f.dst if f else o.dst] = o
+        reduced = {}                    # id(ConvBN) -> (workspace, parts): BN backward sums already taken by a dgrad epilogue
+        ws_busy = [None, None]
+
+        def bnred_targets(t):
+            """BN layers that read grad[t] as their dy: the producer of t and, for a block output, the projection shortcut."""
+            X = conv_of_out.get(t)
+            if X is None:
+                return []
+            out = [X]
+            f = self.fused_add.get(X.dst)
+            if f is not None:
+                p2 = producer.get(f.a)
+                if p2 is not None and id(p2) in early:
+                    out.append(p2)
+            return out
         for pos, op in enumerate(order):
             if isinstance(op, arch.ConvBN):
                 if id(op) in early:     # projection shortcut: its output gradient IS the (masked) block-output gradient
@@ -319,7 +344,13 @@ class EncoderRunner:
                 y = self.act[out_id]
                 red = st.gview(op.name + '_bn_offset')        # [d offset | d scale] adjacent in the flat buffer
                 assert c % 8 == 0 and st.entries[op.name + '_bn_scale'].offset == st.entries[op.name + '_bn_offset'].offset + c
-                plan.add('capmi_bn_bwd_reduce', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']), _p(self.bwd_ws), _p(red), M, c, act, code)
+                if id(op) in reduced:
+                    slot, parts = reduced.pop(id(op))
+                    assert act == NONE
+                    plan.add('capmi_bn_bwd_reduce_final', _p(self.red_ws[slot]), parts, c, _p(red))
+                    ws_busy[slot] = None
+                else:
+                    plan.add('capmi_bn_bwd_reduce', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']), _p(self.bwd_ws), _p(red), M, c, act, code)
                 dres, dres_acc = None, 0
                 if fa is not None and fa.a in shortcut_done:
                     pending.pop(fa.a, None)
@@ -362,10 +393,46 @@ class EncoderRunner:
                     addend = dx if t in written else pending.pop(t, None)
                     mask = is_last and covered and src_act is not None
                     ysaved, dact = (_p(self.act[t]), ACT_CODES[src_act]) if mask else (None, 0)
+                    # this launch completes grad[t] in its final (pre-activation) form: take the BN backward
+                    # sums of the layers that consume it in the same epilogue
+                    targets = bnred_targets(t) if (self.fuse_bn_reduce and is_last and covered and (mask or src_act is None)) else []
+                    launches = []       # (geometry, weight key, Kd)
                     if op.stride == 1:
-                        gd = self._dgrad_geom(op)
-                        Kd = op.k * op.k * op.cout
-                        plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd(op.name + '_weights')), _p(dx), gd, op.cin, Kd, op.cin,
+                        launches.append((self._dgrad_geom(op), op.name + '_weights', op.k * op.k * op.cout))
+                    else:
+                        hi, wi, _ = self.shape[op.src]
+                        for (ph, pw), (d0h, d0w, nkh, nkw) in classes.items():
+                            hc, wc = (hi - ph + op.stride - 1) // op.stride, (wi - pw + op.stride - 1) // op.stride
+                            if d0h != d0w:
+                                raise NotImplementedError('asymmetric parity classes')
+                            # ho = i + d0h + r'  <=>  hn = i*1 - pad' + r' with pad' = -d0h
+                            launches.append((ConvGeom(B, ho, wo, op.cout, hc, wc, nkh, nkw, 1, 1, -d0h, op.cout, op.stride, ph, pw, hi, wi),
+                                             (op.name + '_weights', ph, pw), nkh * nkw * op.cout))
+                    part_rows = [lib().capmi_igemm_nt_bnred_part_rows(gd, op.cin, code) for gd, _, _ in launches] if targets else []
+                    if targets and (min(part_rows) <= 0 or any(ws_busy[q] is not None for q in range(len(targets)))):
+                        targets = []
+                    if targets:
+                        part_off = 0
+                        for (gd, wkey, Kd), pr in zip(launches, part_rows):
+                            tg = []
+                            for q in range(2):
+                                if q < len(targets):
+                                    X = targets[q]
+                                    bq = self.bn[X.dst]
+                                    tg += [_p(self.raw[X.dst]), _p(bq['mean']), _p(bq['invstd']),
+                                           self.red_ws[q].data_ptr() + part_off * 2 * op.cin * 4]
+                                else:
+                                    tg += [None, None, None, None]
+                            plan.add('capmi_igemm_nt_bnred', _p(self.draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin,
+                                     _p(addend), op.cin, ysaved, op.cin, dact, len(targets), *tg, code)
+                            part_off += (gd.B * gd.Ho * gd.Wo + pr - 1) // pr
+                        assert part_off * 2 * op.cin <= self.red_ws[0].numel()
+                        for q, X in enumerate(targets):
+                            reduced[id(X)] = (q, part_off)
+                            ws_busy[q] = id(X)
+                    elif op.stride == 1:
+                        gd, wkey, Kd = launches[0]
+                        plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin,
                                  None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code)
                     else:
                         # strided conv: one dense GEMM per output-parity class over the compact grid,

@@ -57,6 +57,19 @@ def describe(name, args):
         if code == BF16 and bn == 128:
             return 'igemm_nt_glds_kernel<%d>' % bm, 2.0 * M * N * K, nbytes
         return 'igemm_nt_kernel<%s,%d,%d>' % ('bf16' if code == BF16 else 'f32', bm, bn), 2.0 * M * N * K, nbytes
+    if name == 'capmi_igemm_nt_bnred':
+        # (x, w, y, g, N, ldw, ldy, addend, ld_addend, ysaved, ld_saved, dact, nred, 8 target fields, dtype)
+        g = _geom(args[3])
+        N, code, nred = args[4], args[21], args[12]
+        M, K = g.B * g.Ho * g.Wo, g.kh * g.kw * g.Cin
+        es = 2 if code == BF16 else 4
+        bm, bn = _nt_tile(M, N, K, code == BF16)
+        nbytes = g.B * g.Hi * g.Wi * g.Cin * es + N * K * es + M * N * es * (1 + nred + (1 if args[7] else 0) + (1 if args[9] else 0))
+        if code == BF16 and bn == 128:
+            return 'igemm_nt_glds_kernel<%d>' % bm, 2.0 * M * N * K, nbytes
+        return 'igemm_nt_kernel<%s,%d,%d>' % ('bf16' if code == BF16 else 'f32', bm, bn), 2.0 * M * N * K, nbytes
+    if name == 'capmi_bn_bwd_reduce_final':
+        return 'bn_bwd_reduce_final_kernel', 0.0, args[1] * 2 * args[2] * 4
     if name == 'capmi_igemm_tn_wgrad':
         g = _geom(args[3])
         N, code = args[4], args[9]

@@ -176,6 +176,78 @@ def test_strided_dgrad_by_parity_classes(dtype, B, C, H, W, Co, k, pad):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('B,C,H,W,Co,k,s,pad', [(2, 16, 12, 10, 24, 3, 2, 1), (2, 136, 9, 11, 16, 1, 1, 0), (3, 24, 20, 20, 8, 3, 1, 1),
+                                                (2, 32, 8, 8, 16, 1, 2, 0)])
+def test_dgrad_with_fused_bn_backward_sums(dtype, B, C, H, W, Co, k, s, pad):
+    """capmi_igemm_nt_bnred: the data gradient (+ addend, ReLU mask of the completed tensor) and, from the
+    same epilogue, the batch-norm backward sums of TWO layers that read that gradient, finished by
+    capmi_bn_bwd_reduce_final == the separate capmi_bn_bwd_reduce semantics (sum dz, sum dz*xhat)."""
+    _lib, tdt, code = _env()
+    from myimagecaptioningmodel_amd.encoder import dgrad_classes, dgrad_class_offsets
+    rng = np.random.RandomState(B * C + Co + k + s)
+    x = rnd(rng.standard_normal((B, C, H, W)), dtype)
+    w = rnd(rng.standard_normal((Co, C, k, k)) / np.sqrt(C * k * k), dtype)
+    y = O.conv2d_fwd(x, w, s, pad)
+    Ho, Wo = y.shape[2:]
+    dy = rnd(rng.standard_normal(y.shape), dtype)
+    dx, _ = O.conv2d_bwd(dy, x, w, s, pad)
+    covered = not (k == 1 and s == 2)
+    base = rnd(rng.standard_normal((B, H, W, C)), dtype)
+    ysaved = rnd(np.maximum(rng.standard_normal((B, H, W, C)), 0.0), dtype)
+    want_dz = (base + _nhwc(dx)) * (ysaved > 0)
+    raws = [rnd(rng.standard_normal((B, H, W, C)), dtype) for _ in range(2)]
+    means = [rng.standard_normal(C) * 0.3 for _ in range(2)]
+    invs = [np.abs(rng.standard_normal(C)) + 0.5 for _ in range(2)]
+    DY = dev(_nhwc(dy), tdt[dtype])
+    DX = dev(base, tdt[dtype]).clone()
+    YS = dev(ysaved, tdt[dtype])
+    RX = [dev(r, tdt[dtype]) for r in raws]
+    MU = [dev(m, torch.float32) for m in means]
+    IS = [dev(v, torch.float32) for v in invs]
+    launches = []
+    if s == 1:
+        launches.append((_lib.ConvGeom(B, Ho, Wo, Co, H, W, k, k, 1, 1, k - 1 - pad, Co), np.flip(w, (2, 3)).transpose(1, 2, 3, 0)))
+    else:
+        offs = dgrad_class_offsets(k, s, pad)
+        for (ph, pw, rmap, qmap) in dgrad_classes(k, s, pad):
+            d0h, d0w, nkh, nkw = offs[(ph, pw)]
+            wc = np.zeros((C, nkh, nkw, Co))
+            for a_, r in enumerate(rmap):
+                for b_, q in enumerate(qmap):
+                    wc[:, a_, b_, :] = w[:, :, r, q].T
+            hc, wcc = (H - ph + s - 1) // s, (W - pw + s - 1) // s
+            launches.append((_lib.ConvGeom(B, Ho, Wo, Co, hc, wcc, nkh, nkw, 1, 1, -d0h, Co, s, ph, pw, H, W), wc))
+    rows = [(_lib.lib().capmi_igemm_nt_bnred_part_rows(g, C, code[dtype])) for g, _ in launches]
+    assert min(rows) > 0
+    parts = [(g.B * g.Ho * g.Wo + r - 1) // r for (g, _), r in zip(launches, rows)]
+    WS = [torch.full((sum(parts) * 2 * C,), float('nan'), device=DEV) for _ in range(2)]
+    _KEEP.extend(WS)
+    off = 0
+    for (g, wc), np_ in zip(launches, parts):
+        _lib.call('capmi_igemm_nt_bnred', p(DY), p(dev(np.ascontiguousarray(wc), tdt[dtype])), p(DX), g, C, g.kh * g.kw * Co, C,
+                  p(DX), C, p(YS), C, _lib.ACT_RELU, 2,
+                  p(RX[0]), p(MU[0]), p(IS[0]), WS[0].data_ptr() + off * 2 * C * 4,
+                  p(RX[1]), p(MU[1]), p(IS[1]), WS[1].data_ptr() + off * 2 * C * 4, code[dtype], stream())
+        off += np_
+    got_dz = host(DX)
+    if covered:
+        check(got_dz, want_dz, dtype, name='masked dgrad')
+        sel = np.ones((B, H, W, 1), bool)
+    else:           # only the class pixels are rewritten (and summed); the others keep `base`
+        sel = np.zeros((B, H, W, 1), bool)
+        sel[:, ::2, ::2] = True
+        check(got_dz, np.where(sel, want_dz, base), dtype, name='masked dgrad (class pixels)')
+    dzr = got_dz * sel                 # sums are defined on the values the kernel stored
+    for q in range(2):
+        red = torch.zeros(2 * C, device=DEV)
+        _KEEP.append(red)
+        _lib.call('capmi_bn_bwd_reduce_final', p(WS[q]), sum(parts), C, p(red), stream())
+        want = np.concatenate([dzr.sum((0, 1, 2)), (dzr * (raws[q] - means[q].astype(np.float32)) * invs[q].astype(np.float32)).sum((0, 1, 2))])
+        check(host(red), want, 'f32' if dtype == 'f32' else 'bf16', scale=np.abs(want).max(), name='fused BN sums %d' % q)
+        assert np.abs(host(red) - want).max() <= 2e-3 * np.abs(want).max() + 1e-3, 'fused BN sums %d' % q
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(1216, 40, 48), (64, 264, 136), (5000, 16, 24), (333, 1000, 32)])
 def test_fc_wgrad_and_colsum(dtype, M, N, K):
     _lib, tdt, code = _env()
