@@ -1040,6 +1040,39 @@ __device__ __forceinline__ void load_frag_tr(Frag<float>& f, const float* tile, 
     for (int j = 0; j < 8; ++j) f.v[j] = tile[(8 * g + j) * LD + col16 + i];
 }
 
+template <int BNO, int BKO, int TN_, int TK_>
+__device__ __forceinline__ void tn_epilogue(const WGradArgs& a, f32x4 (&acc)[TN_][TK_], int n0, int k0, int split, int wn, int wk, int fr, int fg) {
+    if (a.slab) {
+        // partial tile -> slab[split][k][n] (transposed): the accumulator quad of a lane is 4
+        // consecutive n of one k, i.e. one 16-byte store; no atomics (wgrad_reduce_kernel sums the splits)
+        float* sl = a.slab + (size_t)split * a.Kp * a.Np;
+#pragma unroll
+        for (int i = 0; i < TN_; ++i)
+#pragma unroll
+            for (int j = 0; j < TK_; ++j) {
+                const int k = k0 + wk * (TK_ * 16) + j * 16 + fr;
+                const int n = n0 + wn * (TN_ * 16) + i * 16 + fg * 4;
+                *reinterpret_cast<f32x4*>(&sl[(size_t)k * a.Np + n]) = acc[i][j];
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < TN_; ++i)
+#pragma unroll
+        for (int j = 0; j < TK_; ++j) {
+            const int k = k0 + wk * (TK_ * 16) + j * 16 + fr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * (TN_ * 16) + i * 16 + fg * 4 + r;
+                if (n < a.N && k < a.K) {
+                    float* p = &a.dw[(int64_t)n * a.lddw + k];
+                    if (a.splits == 1) *p += acc[i][j][r];          // single split: sole contributor
+                    else atomicAdd(p, acc[i][j][r]);                 // small outputs (64x64 tiles): few bytes, direct atomics
+                }
+            }
+        }
+}
+
 template <typename T, int BNO, int BKO>
 __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
     constexpr int RM = 64;                      // reduction rows per step: one LDS stage + one stage in registers
@@ -1126,35 +1159,121 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
                 for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[i], bf[j]);
         }
     }
-    if (a.slab) {
-        // partial tile -> slab[split][k][n] (transposed): the accumulator quad of a lane is 4
-        // consecutive n of one k, i.e. one 16-byte store; no atomics (wgrad_reduce_kernel sums the splits)
-        float* sl = a.slab + (size_t)split * a.Kp * a.Np;
-#pragma unroll
-        for (int i = 0; i < TN_; ++i)
-#pragma unroll
-            for (int j = 0; j < TK_; ++j) {
-                const int k = k0 + wk * (BKO / 2) + j * 16 + fr;
-                const int n = n0 + wn * (BNO / 2) + i * 16 + fg * 4;
-                *reinterpret_cast<f32x4*>(&sl[(size_t)k * a.Np + n]) = acc[i][j];
+    tn_epilogue<BNO, BKO, TN_, TK_>(a, acc, n0, k0, split, wn, wk, fr, fg);
+}
+
+// LDS-DMA form of the weight-gradient kernel (bf16, 128 x 128 output tile, 32 reduction rows per stage,
+// 3-stage ring, no staging registers): the kernel is bound by bytes in flight from L2, not by MFMA or
+// LDS.  A stage holds dY [32][128] and X(im2col) [32][128] as unpadded 256-byte rows; a DMA wave
+// instruction fills 4 rows.  ds_read_b64_tr_b16 touches 16 rows x 32 B per instruction, so the 16-byte
+// chunk c of row r sits at position c ^ f(r), f(r) = (r & 3) | ((r >> 3) & 3) << 2 (applied on the
+// SOURCE address of the DMA): the 16 rows of a transposing read then cover all 64 banks twice.
+__device__ __forceinline__ void load_frag_tr_swz(Frag<bf16>& f, const char* tile, int g, int col16, int i) {
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int fsw = (i >> 2) | (g << 2);
+    const int bytecol = col16 * 2 + (i & 3) * 8;
+    const char* p0 = tile + (8 * g + (i >> 2)) * 256 + ((((bytecol >> 4) ^ fsw) << 4) | (bytecol & 15));
+    const char* p1 = p0 + 4 * 256;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    f.v = __builtin_bit_cast(bf16x8, both);
+}
+
+__global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
+    // 8 waves: 2 (n) x 4 (k), each a 64 x 32 sub-tile -- the loop is bound by per-wave instruction issue
+    // and LDS/MFMA latency, so the same tile and LDS footprint is shared by twice the waves
+    typedef bf16 T;
+    constexpr int BNO = 128, BKO = 128, RM = 32, NST = 3;
+    constexpr int OPB = RM * 256, STB = 2 * OPB;            // bytes per operand tile / per stage
+    constexpr int TN_ = 4, TK_ = 2;
+    __shared__ __attribute__((aligned(1024))) char smem[NST * STB];
+
+    const T* __restrict__ X = (const T*)a.x;
+    const T* __restrict__ DY = (const T*)a.dy;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 2, wk = wave & 3;
+    const int tiles_k = (a.K + BKO - 1) / BKO;
+    const int tiles = tiles_k * ((a.N + BNO - 1) / BNO);
+    const int id = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int split = id / tiles, tl = id - split * tiles;
+    const int n0 = (tl / tiles_k) * BNO;
+    const int k0 = (tl % tiles_k) * BKO;
+    const int m_begin = split * a.m_per_split;
+    const int m_end = min(a.M, m_begin + a.m_per_split);
+    if (m_begin >= m_end) return;
+
+    // this thread's DMA slot: row 4*wave + (lane >> 4), LDS chunk position lane & 15
+    // = global chunk (lane & 15) ^ f(row)
+    const int chunk = (lane & 15) ^ ((lane >> 4) | (((wave >> 1) & 3) << 2));
+    const int ncol = n0 + chunk * 8;
+    const KPos kp = k_pos(k0 + chunk * 8, a.g);             // fixed for the whole kernel
+    const bool yok = ncol < a.N, xok = kp.k < a.K;
+    const int r0 = 4 * wave + (lane >> 4);
+    const T* zero = reinterpret_cast<const T*>(capmi_zero_page);
+
+    // branch-free addressing (selects only): the loop is bound by instruction issue, not by memory
+    const int tap_h = kp.r - a.g.pad, tap_w = kp.q - a.g.pad;       // input row = ho*sd + tap_h
+    const int sd = a.g.sd, Hi = a.g.Hi, Wi = a.g.Wi, ldx = a.g.ldx, ldy = a.ldy;
+    auto issue_stage = [&](int st, int mt) {
+        char* base = smem + st * STB + wave * 1024;
+        constexpr int j = 0;
+        {
+            const int m = mt + r0;
+            const bool ok = m < m_end;
+            const T* ysrc = DY + (int64_t)m * ldy + ncol;
+            ysrc = (ok && yok) ? ysrc : zero;
+            const T* xsrc;
+            if (a.linear) {         // 1x1 / stride 1: A(m, k) = x[m][k]
+                xsrc = X + ((int64_t)m * ldx + kp.k);
+                xsrc = (ok && xok) ? xsrc : zero;
+            } else {
+                const int b = fdiv(m, a.fd_hw), rem = m - b * a.fd_hw.d;
+                const int ho = fdiv(rem, a.fd_w), wo = rem - ho * a.fd_w.d;
+                const int hn = ho * sd + tap_h, wn = wo * sd + tap_w;
+                const bool okx = ok && xok && (unsigned)hn < (unsigned)Hi && (unsigned)wn < (unsigned)Wi;
+                xsrc = X + ((int64_t)((b * Hi + hn) * Wi + wn) * ldx + kp.c);
+                xsrc = okx ? xsrc : zero;
             }
-        return;
-    }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ysrc,
+                                             (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
+                                             (__attribute__((address_space(3))) void*)(base + OPB + j * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TN_][TK_];
 #pragma unroll
     for (int i = 0; i < TN_; ++i)
 #pragma unroll
-        for (int j = 0; j < TK_; ++j) {
-            const int k = k0 + wk * (BKO / 2) + j * 16 + fr;
+        for (int j = 0; j < TK_; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nsteps = (m_end - m_begin + RM - 1) / RM;
+    auto rows_of = [&](int step) { return step < nsteps ? m_begin + step * RM : m_end; };   // >= m_end: nothing to load
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * (BNO / 2) + i * 16 + fg * 4 + r;
-                if (n < a.N && k < a.K) {
-                    float* p = &a.dw[(int64_t)n * a.lddw + k];
-                    if (a.splits == 1) *p += acc[i][j][r];          // single split: sole contributor
-                    else atomicAdd(p, acc[i][j][r]);                 // small outputs (64x64 tiles): few bytes, direct atomics
-                }
-            }
-        }
+    for (int p = 0; p < NST - 1; ++p) issue_stage(p, rows_of(p));
+    int slot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        wait_vmcnt<(NST - 2) * 2>();                          // this thread's part of stage s has landed
+        __builtin_amdgcn_s_barrier();                         // ... everyone's; all waves are done with stage s-1
+        asm volatile("" ::: "memory");
+        issue_stage(slot == 0 ? NST - 1 : slot - 1, rows_of(s + NST - 1));
+        const char* st = smem + slot * STB;
+        slot = slot + 1 == NST ? 0 : slot + 1;
+        Frag<T> af[TN_], bf[TK_];
+#pragma unroll
+        for (int i = 0; i < TN_; ++i) load_frag_tr_swz(af[i], st, fg, wn * 64 + i * 16, fr);
+#pragma unroll
+        for (int j = 0; j < TK_; ++j) load_frag_tr_swz(bf[j], st + OPB, fg, wk * 32 + j * 16, fr);
+#pragma unroll
+        for (int i = 0; i < TN_; ++i)
+#pragma unroll
+            for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[i], bf[j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tn_epilogue<BNO, BKO, TN_, TK_>(a, acc, n0, k0, split, wn, wk, fr, fg);
 }
 
 // dw[n][k] += sum_s slab[s][k][n]: 32x32 tiles, coalesced reads along n, LDS transpose, coalesced writes along k
@@ -1178,15 +1297,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// Splits over the reduction (pixel) axis: enough workgroups for ~3 per CU, every split >= 4 steps
-// (256 rows) deep, and the partial slabs (tiles x splits x tile elements) capped at 6 M floats
-// (24 MB: ~4 us to store, ~5 us to read back).
+// Splits over the reduction (pixel) axis: as many as fit in ONE round of resident workgroups (3 per CU
+// for the 128x128 LDS-DMA kernel, 4 for the 64x64 one) -- one workgroup more than that costs a whole
+// second round --, every split >= 256 rows deep, and the partial slabs (tiles x splits x tile elements)
+// capped at 6 M floats (24 MB: ~4 us to store, ~5 us to read back).
 static int tn_splits(int M, int N, int K, int bno, int bko, int* per_out) {
     const int tiles = cdiv(N, bno) * cdiv(K, bko);
     const long long out_elems = (long long)cdiv(N, bno) * bno * cdiv(K, bko) * bko;
     long long by_ws = (6ll << 20) / (out_elems > 0 ? out_elems : 1);
     if (by_ws < 1) by_ws = 1;
-    int want = cdiv(768, tiles);
+    const int slots = 256 * (bno >= 128 ? 3 : 4);
+    int want = slots / tiles;
     int max_splits = cdiv(M, 256);
     if (max_splits > by_ws) max_splits = (int)by_ws;
     int splits = want < 1 ? 1 : (want > max_splits ? max_splits : want);
@@ -1226,7 +1347,8 @@ static int launch_tn(WGradArgs& a, float* ws, long long ws_bytes, hipStream_t st
                     (long long)splits * a.Np * a.Kp * 4);
         a.slab = ws;
     }
-    hipLaunchKernelGGL((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles * splits), dim3(256), 0, st, a);
+    if constexpr (sizeof(T) == 2 && BNO == 128) hipLaunchKernelGGL(igemm_tn_glds_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles * splits), dim3(256), 0, st, a);
     if (use_slab)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.Np / 32, a.Kp / 32), dim3(256), 0, st, ws, splits, a.Np, a.Kp, a.dw, a.N, a.K, a.lddw);
     CAPMI_LAUNCH_CHECK("capmi_igemm_tn_wgrad");
@@ -1245,6 +1367,7 @@ extern "C" int capmi_igemm_tn_wgrad(const void* x, const void* dy, float* dw, co
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldy = ldy; a.lddw = lddw; a.g = *g; a.m_per_split = a.M;
     CAPMI_CHECK((long long)(a.M + 256) * g->Ho * g->Wo < (1ll << 40), "capmi_igemm_tn_wgrad: M * Ho*Wo outside the fast-division range");
+    CAPMI_CHECK((long long)(g->B + 1) * g->Hi * g->Wi < (1ll << 31), "capmi_igemm_tn_wgrad: more than 2^31 input pixels");
     a.fd_hw = fast_div(g->Ho * g->Wo); a.fd_w = fast_div(g->Wo);
     a.linear = (g->kh == 1 && g->kw == 1 && g->sd == 1 && g->up == 1 && g->pad == 0 && g->Hi == g->Ho && g->Wi == g->Wo) ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;

@@ -77,7 +77,9 @@ def describe(name, args):
         es = 2 if code == BF16 else 4
         big = N >= 128 and K >= 128 and code == BF16
         nbytes = g.B * g.Hi * g.Wi * g.Cin * es + M * N * es + N * K * 4
-        return 'igemm_tn_kernel<%s,%s>' % ('bf16' if code == BF16 else 'f32', '128,128' if big else '64,64'), 2.0 * M * N * K, nbytes
+        if big:
+            return 'igemm_tn_glds_kernel', 2.0 * M * N * K, nbytes
+        return 'igemm_tn_kernel<%s,64,64>' % ('bf16' if code == BF16 else 'f32'), 2.0 * M * N * K, nbytes
     es_of = lambda code: 2 if code == BF16 else 4
     if name == 'capmi_bn_apply':
         M, C, code = args[6], args[7], args[9]
