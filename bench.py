@@ -53,13 +53,13 @@ def pmc_traffic(label):
         return None
     kernels = json.load(open(files[-1]))['kernels']
     m = re.match(r'(igemm_(nt|tn)_kernel)<(bf16|f32),(\d+),(\d+)>', label)
-    g = re.match(r'igemm_nt_glds_kernel<(\d+)>', label)
+    g = re.match(r'igemm_nt_glds_kernel<(\d+),(\d+)>', label)
     if m:
         pre = '_Z15%sI%sLi%sELi%sE' % (m.group(1), 'DF16b' if m.group(3) == 'bf16' else 'f', m.group(4), m.group(5))
         hit = [v for k, v in kernels.items() if k.startswith(pre) or k.replace(' ', '').startswith('void' + label.replace('bf16', '__hip_bfloat16')[:-1])]
     elif g:
-        hit = [v for k, v in kernels.items() if k.startswith('_Z20igemm_nt_glds_kernelILi%sEE' % g.group(1))
-               or ('igemm_nt_glds_kernel<%s>' % g.group(1)) in k]
+        hit = [v for k, v in kernels.items() if ('igemm_nt_glds_kernel<%s, %s,' % (g.group(1), g.group(2))) in k
+               or k.startswith('_Z20igemm_nt_glds_kernelILi%sELi%sE' % (g.group(1), g.group(2)))]
     else:
         hit = [v for k, v in kernels.items() if label.replace('_kernel', '') in k]
     return round(hit[0]['hbm_bytes_per_launch'] / 1e6, 3) if hit else None       # MB per launch

@@ -235,7 +235,7 @@ int capmi_cast(const float* src, void* dst, int64_t n, int dtype, void* stream);
 int capmi_weight_dgrad_form(const float* w, void* wt, int N, int kh, int kw, int C, int ldt, int dtype, void* stream);
 /* The same for every GEMM weight of a model in one launch.  jobs: device array of
  *   struct { int64 src_off, dst_off; int32 N, kh, kw, C, ldt, first, okh, okw; int8 rmap[4], qmap[4]; }
- * (56 bytes, one per run of 16 tiles of one weight's output -- a tile is 64 n x 64 c of one tap,
+ * (56 bytes, one per run of 2 tiles of one weight's output -- a tile is 64 n x 64 c of one tap,
  * tile index = (tap * ceil(C/64) + ct) * ceil(ldt/64) + nt, `first` = the run's first tile;
  * offsets in elements into `flat` (f32) / `shadow` (`dtype`)).  Output is [C][okh][okw][ldt] with tap (r',q') taken from source tap
  * (rmap[r'], qmap[q']): the plain data-gradient form is okh=kh, rmap[r'] = kh-1-r'; the parity

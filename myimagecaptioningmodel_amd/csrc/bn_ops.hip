@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
     const int m_begin = blockIdx.x * L.rows_per_block;
     const int m_end = min(M, m_begin + L.rows_per_block);
-#pragma unroll 4
+#pragma unroll 8
     for (int m = m_begin + rr; m < m_end; m += L.rp) {
         const int64_t off = (int64_t)m * C + chunk * VEC;
         Vec<T> xv = vload<T>(x + off), rv, ov;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (int v = 0; v < VEC; ++v) { mu[v] = mean[chunk * VEC + v]; is[v] = invstd[chunk * VEC + v]; }
         const int m_begin = blockIdx.x * L.rows_per_block;
         const int m_end = min(M, m_begin + L.rows_per_block);
-#pragma unroll 4
+#pragma unroll 8
         for (int m = m_begin + rr; m < m_end; m += L.rp) {
             const int64_t off = (int64_t)m * C + chunk * VEC;
             Vec<T> dv = vload<T>(dy + off), xv = vload<T>(x + off), yv;

@@ -653,16 +653,16 @@ __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int NST, bool RED = false>
+template <int BM, int BN, int NST, bool RED = false>
 __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_kernel(IGemmArgs a) {
     typedef bf16 T;
-    constexpr int BN = 128, BK = 32, WMW = 4;
-    constexpr int TM = BM / 64, TN = 8;                 // 4x1 waves: BM/4 rows x 128 columns each
+    constexpr int BK = 32, WMW = 4;
+    constexpr int TM = BM / 64, TN = BN / 16;           // 4x1 waves: BM/4 rows x BN columns each
     constexpr int AOPB = BM * BK * 2, BOPB = BN * BK * 2;   // bytes of the A / B operand tiles
-    constexpr int STB = AOPB + BOPB;                    // bytes per stage (16 KiB / 12 KiB)
-    constexpr int ACNT = BM / 64, BCNT = 2;             // DMA instructions per thread per stage
+    constexpr int STB = AOPB + BOPB;                    // bytes per stage
+    constexpr int ACNT = BM / 64, BCNT = BN / 64;       // DMA instructions per thread per stage
     constexpr int NGL = ACNT + BCNT;
-    __shared__ __attribute__((aligned(1024))) char smem[NST * STB];
+    __shared__ __attribute__((aligned(1024))) char smem[NST * STB < 4096 ? 4096 : NST * STB];
 
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ W = (const T*)a.w;
@@ -683,13 +683,12 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
 #pragma unroll
     for (int i = 0; i < BCNT; ++i) {
         const int l = i * 64 + (tid >> 2);
-        const int n = n0 + 8 * (l & 15) + (l >> 4);     // LDS row j*16+fr holds weight column TN*fr + j
+        const int n = n0 + TN * (l & 15) + (l >> 4);    // LDS row j*16+fr holds weight column TN*fr + j
         wok[i] = n < a.N;
         wrow[i] = W + (int64_t)(wok[i] ? n : 0) * a.ldw;
     }
     KPos kp = k_pos(chunk * 8, a.g);
     const T* zero = reinterpret_cast<const T*>(capmi_zero_page);
-
     auto issue_stage = [&](int st) {    // DMA of the tile at the current kp into ring slot st; advances kp
         char* base = smem + st * STB + wave * 1024;
 #pragma unroll
@@ -889,6 +888,7 @@ static NtCfg nt_cfg(int M, int N, int K, int dtype) {
     if (dtype == CAPMI_BF16) {
         if (wide) {
             const bool big = K >= 512 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 384;   // LDS-DMA pipeline kernel: deep K, full grid
+            if (!big && (int64_t)cdiv(M, 64) * cdiv(N, 128) < 256) return NtCfg{64, 64, 5};      // under-filled grid: 64x64 LDS-DMA tiles (wmw 5 = marker)
             return NtCfg{big ? 128 : 64, 128, 4};
         }
         const bool tall = cdiv(M, 128) >= 512;
@@ -961,13 +961,20 @@ static int igemm_nt_impl(const void* x, const void* w, void* y, const capmi_conv
     }
     const NtCfg c = nt_cfg(a.M, N, a.K, dtype);
     if (dtype == CAPMI_BF16) {
+        if (c.wmw == 5) {       // 64x64 LDS-DMA tiles
+            const int64_t tiles = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64);
+            if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 64, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 64, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds64x64)");
+            return 0;
+        }
         if (c.bn == 128) {      // LDS-DMA pipeline kernels
             const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(a.N, 128);
             CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
-            if (c.bm == 128 && a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            if (c.bm == 128 && a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 128, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 128, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 128, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 128, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
             return 0;
         }

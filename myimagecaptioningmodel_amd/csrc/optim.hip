@@ -78,7 +78,7 @@ extern "C" int capmi_weight_dgrad_form(const float* w, void* wt, int N, int kh, 
 }
 
 // All data-gradient weight forms of a model in ONE launch: a job table in device memory, one job per
-// (weight, run of 16 tiles); a tile is 64 output channels x 64 input channels of one tap, transposed
+// (weight, run of 2 tiles); a tile is 64 output channels x 64 input channels of one tap, transposed
 // through LDS so that both the f32 reads (along c) and the low-precision writes (along n) are coalesced.
 struct DgradJob {
     long long src_off, dst_off;     // element offsets into the f32 master / the shadow buffer
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void dgrad_form_batched_kernel(const float* __
     const float* w = flat + j.src_off;
     T* wt = shadow + j.dst_off;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int last = min(total, j.first + 16);
+    const int last = min(total, j.first + 2);
     for (int t = j.first; t < last; ++t) {
         const int nt = t % ntiles, ct = (t / ntiles) % ctiles, tap = t / (ntiles * ctiles);
         const int q = tap % j.okw, r = tap / j.okw;

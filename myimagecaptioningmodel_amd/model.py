@@ -104,12 +104,12 @@ class CaptionEngine:
         self.shadow_plan = Plan()
         if self.code == BF16:
             self.shadow_plan.add('capmi_cast', _p(st.flat), _p(self.low), st.size, self.code)
-        # one launch for every data-gradient form: job table = one entry per run of 16 64x64 tiles
+        # one launch for every data-gradient form: job table = one entry per run of 2 64x64 tiles
         jobs = []
         for key, (o, (n, kh, kw, c, ldt), rmap, qmap) in self.wT_entries.items():
             name = key if isinstance(key, str) else key[0]
             total = len(rmap) * len(qmap) * ((c + 63) // 64) * ((ldt + 63) // 64)
-            for first in range(0, total, 16):
+            for first in range(0, total, 2):
                 jobs.append((st.entries[name].offset, o, n, kh, kw, c, ldt, first, len(rmap), len(qmap),
                              (list(rmap) + [0] * 4)[:4], (list(qmap) + [0] * 4)[:4]))
         table = np.zeros(len(jobs), dtype=np.dtype([('src', '<i8'), ('dst', '<i8'), ('N', '<i4'), ('kh', '<i4'), ('kw', '<i4'),

@@ -31,10 +31,12 @@ def _nt_tile(M, N, K, bf16):
     if bf16:
         if wide:
             big = K >= 512 and cd(M, 128) * cd(N, 128) >= 384
-            return (128 if big else 64, 128)
-        return (128 if cd(M, 128) >= 512 else 64, 64)
+            if not big and cd(M, 64) * cd(N, 128) < 256:
+                return (64, 64, True)
+            return (128 if big else 64, 128, True)
+        return (128 if cd(M, 128) >= 512 else 64, 64, False)
     tall = cd(M, 128) * cd(N, 64) >= 256
-    return (64, 128) if wide else ((128 if tall else 64), 64)
+    return (64, 128, False) if wide else ((128 if tall else 64), 64, False)
 
 
 def describe(name, args):
@@ -44,7 +46,7 @@ def describe(name, args):
         N, code, out_f32 = args[4], args[16], args[15]
         M, K = g.B * g.Ho * g.Wo, g.kh * g.kw * g.Cin
         es = 2 if code == BF16 else 4
-        bm, bn = _nt_tile(M, N, K, code == BF16)
+        bm, bn, glds = _nt_tile(M, N, K, code == BF16)
         plain = g.kh == 1 and g.kw == 1 and g.sd == 1 and g.up == 1 and g.pad == 0 and g.Hi == 1 and g.Wi == 1
         if plain and not args[12] and M <= 64 and K % 128 == 0 and K >= 256:
             return 'igemm_nt_skinny_kernel<%s>' % ('bf16' if code == BF16 else 'f32'), 2.0 * M * N * K, (M * K + N * K + M * N) * es
@@ -54,8 +56,8 @@ def describe(name, args):
             nbytes += M * N * es
         if args[10]:
             nbytes += M * N * es
-        if code == BF16 and bn == 128:
-            return 'igemm_nt_glds_kernel<%d>' % bm, 2.0 * M * N * K, nbytes
+        if glds:
+            return 'igemm_nt_glds_kernel<%d,%d>' % (bm, bn), 2.0 * M * N * K, nbytes
         return 'igemm_nt_kernel<%s,%d,%d>' % ('bf16' if code == BF16 else 'f32', bm, bn), 2.0 * M * N * K, nbytes
     if name == 'capmi_igemm_nt_bnred':
         # (x, w, y, g, N, ldw, ldy, addend, ld_addend, ysaved, ld_saved, dact, nred, 8 target fields, dtype)
@@ -63,10 +65,10 @@ def describe(name, args):
         N, code, nred = args[4], args[21], args[12]
         M, K = g.B * g.Ho * g.Wo, g.kh * g.kw * g.Cin
         es = 2 if code == BF16 else 4
-        bm, bn = _nt_tile(M, N, K, code == BF16)
+        bm, bn, glds = _nt_tile(M, N, K, code == BF16)
         nbytes = g.B * g.Hi * g.Wi * g.Cin * es + N * K * es + M * N * es * (1 + nred + (1 if args[7] else 0) + (1 if args[9] else 0))
-        if code == BF16 and bn == 128:
-            return 'igemm_nt_glds_kernel<%d>' % bm, 2.0 * M * N * K, nbytes
+        if glds:
+            return 'igemm_nt_glds_kernel<%d,%d>' % (bm, bn), 2.0 * M * N * K, nbytes
         return 'igemm_nt_kernel<%s,%d,%d>' % ('bf16' if code == BF16 else 'f32', bm, bn), 2.0 * M * N * K, nbytes
     if name == 'capmi_bn_bwd_reduce_final':
         return 'bn_bwd_reduce_final_kernel', 0.0, args[1] * 2 * args[2] * 4
