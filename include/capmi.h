@@ -64,6 +64,19 @@ int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom*
                    const void* ysaved, int ld_saved, float* stats,
                    int act, int dact, int out_f32, int dtype, void* stream);
 
+/* Several independent capmi_igemm_nt products with disjoint outputs (the output-parity classes of a
+ * strided convolution's data gradient: small GEMMs that under-fill the chip one at a time), issued
+ * together.  Semantics = the calls one after another (bias, statistics, act off, output in `dtype`);
+ * eligible groups (bf16, N > 64) run as ONE launch, anything else falls back to per-call launches. */
+typedef struct capmi_igemm_nt_call {
+    const void* x; const void* w; void* y;
+    capmi_conv_geom g;
+    int N, ldw, ldy;
+    const void* addend; int ld_addend;
+    const void* ysaved; int ld_saved; int dact;
+} capmi_igemm_nt_call;
+int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count, int dtype, void* stream);
+
 /* Data-gradient GEMM whose OUTPUT completes the gradient of a batch-normalised tensor: capmi_igemm_nt
  * (bias, act, statistics off; output dense, ldy == N) plus, in the same epilogue, the first stage of
  * capmi_bn_bwd_reduce for the `nred` (1 or 2) layers that take this output as their dy (the layer

@@ -20,6 +20,14 @@ class ConvGeom(ctypes.Structure):
                 ('B', 'Hi', 'Wi', 'Cin', 'Ho', 'Wo', 'kh', 'kw', 'sd', 'up', 'pad', 'ldx', 'os', 'oh0', 'ow0', 'Hof', 'Wof')]
 
 
+class NtCall(ctypes.Structure):
+    """capmi_igemm_nt_call (include/capmi.h)."""
+    _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p), ('g', ConvGeom),
+                ('N', ctypes.c_int), ('ldw', ctypes.c_int), ('ldy', ctypes.c_int),
+                ('addend', ctypes.c_void_p), ('ld_addend', ctypes.c_int),
+                ('ysaved', ctypes.c_void_p), ('ld_saved', ctypes.c_int), ('dact', ctypes.c_int)]
+
+
 def gemm_geom(rows, K, ldx=None):
     """Geometry of a plain row-major GEMM A[rows][K] (row stride ldx)."""
     return ConvGeom(rows, 1, 1, K, 1, 1, 1, 1, 1, 1, 0, K if ldx is None else ldx)
@@ -32,6 +40,7 @@ _g = ctypes.POINTER(ConvGeom)
 SIGNATURES = {
     'capmi_igemm_nt': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
     'capmi_igemm_nt_bnred': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    'capmi_igemm_nt_group': [ctypes.POINTER(NtCall), _i, _i, _p],
     'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
     'capmi_colsum': [_p, _i, _i, _i, _p, _i, _p],
     'capmi_im2col_stem': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],

@@ -653,8 +653,8 @@ __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NST, bool RED = false>
-__global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_kernel(IGemmArgs a) {
+template <int BM, int BN, int NST, bool RED>
+__device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int nblocks) {
     typedef bf16 T;
     constexpr int BK = 32, WMW = 4;
     constexpr int TM = BM / 64, TN = BN / 16;           // 4x1 waves: BM/4 rows x BN columns each
@@ -668,9 +668,10 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
     const T* __restrict__ W = (const T*)a.w;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (a.N + BN - 1) / BN;
-    const int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile = xcd_swizzle(block, nblocks);
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
+    if (m0 >= a.M) return;              // padding block of a grouped launch
 
     // this thread's DMA slots: rows (tid>>2) [+64], LDS chunk position tid&3, i.e. global chunk
     // (tid&3) ^ ((tid>>4)&3) of that row ((row>>2)&3 is the same for row and row+64)
@@ -752,6 +753,28 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the (zero-page) tail stages before LDS reuse
     __syncthreads();
     nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
+}
+
+template <int BM, int BN, int NST, bool RED = false>
+__global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_kernel(IGemmArgs a) {
+    nt_glds_body<BM, BN, NST, RED>(a, blockIdx.x, gridDim.x);
+}
+
+// Several independent problems (the parity classes of a strided data gradient) in ONE launch: the
+// classes are small GEMMs that under-fill the chip one by one.  Block ranges start at multiples of 8 so
+// that the XCD-contiguous tile order holds inside every problem.
+constexpr int NT_GROUP_MAX = 4;
+struct NtGroup {
+    IGemmArgs a[NT_GROUP_MAX];
+    int first[NT_GROUP_MAX + 1];
+    int count;
+};
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_group_kernel(NtGroup g) {
+    const int b = blockIdx.x;
+    int p = 0;
+    while (p + 1 < g.count && b >= g.first[p + 1]) ++p;
+    nt_glds_body<BM, BN, NST, false>(g.a[p], b - g.first[p], g.first[p + 1] - g.first[p]);
 }
 
 // ------------------------------------------------------------------ skinny NT kernel (M <= 64)
@@ -920,10 +943,10 @@ static bool nt_uses_skinny(const capmi_conv_geom* g, int M, int K, bool stats, i
     return plain && g->os <= 1 && !stats && M <= 64 && K % 128 == 0 && K >= 256 && (dtype == CAPMI_BF16 || dtype == CAPMI_F32);
 }
 
-static int igemm_nt_impl(const void* x, const void* w, void* y, const capmi_conv_geom* g,
-                         int N, int ldw, int ldy, const float* bias, const void* addend,
-                         int ld_addend, const void* ysaved, int ld_saved, float* stats,
-                         int act, int dact, int out_f32, int nred, const BnRedTarget* red, int dtype, void* stream) {
+static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const capmi_conv_geom* g,
+                      int N, int ldw, int ldy, const float* bias, const void* addend,
+                      int ld_addend, const void* ysaved, int ld_saved, float* stats,
+                      int act, int dact, int out_f32, int nred, const BnRedTarget* red, int dtype) {
     CAPMI_CHECK(x && w && y && g, "capmi_igemm_nt: null pointer");
     const int vec = dtype == CAPMI_F32 ? 4 : 8;
     CAPMI_CHECK(g->Cin % vec == 0 && g->ldx % vec == 0 && ldw % vec == 0,
@@ -934,7 +957,6 @@ static int igemm_nt_impl(const void* x, const void* w, void* y, const capmi_conv
     CAPMI_CHECK(!(stats && addend), "capmi_igemm_nt: fused statistics and addend are mutually exclusive");
     CAPMI_CHECK(g->os <= 1 || (!stats && g->Hof > 0 && g->Wof > 0 && (g->Ho - 1) * g->os + g->oh0 < g->Hof && (g->Wo - 1) * g->os + g->ow0 < g->Wof),
                 "capmi_igemm_nt: bad output-scatter geometry");
-    IGemmArgs a;
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.addend = addend; a.ysaved = ysaved; a.stats = stats;
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldw = ldw; a.ldy = ldy; a.ld_addend = ld_addend; a.ld_saved = ld_saved;
@@ -950,7 +972,10 @@ static int igemm_nt_impl(const void* x, const void* w, void* y, const capmi_conv
     a.stamps = g_stamp_buffer;
 #endif
     CAPMI_CHECK(ldw >= a.K, "capmi_igemm_nt: ldw=%d < K=%d", ldw, a.K);
-    hipStream_t st = (hipStream_t)stream;
+    return 0;
+}
+
+static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, float* stats, int nred, int dtype, hipStream_t st) {
     if (nt_uses_skinny(g, a.M, a.K, stats != nullptr, dtype)) {
         CAPMI_CHECK(nred == 0, "capmi_igemm_nt_bnred: not available for M <= 64 plain products (see capmi_igemm_nt_bnred_part_rows)");
         // decoder recurrence and other M <= 64 products: skinny kernel (64x32 tiles, K split over waves)
@@ -989,6 +1014,16 @@ static int igemm_nt_impl(const void* x, const void* w, void* y, const capmi_conv
     return 1;
 }
 
+
+static int igemm_nt_impl(const void* x, const void* w, void* y, const capmi_conv_geom* g,
+                         int N, int ldw, int ldy, const float* bias, const void* addend,
+                         int ld_addend, const void* ysaved, int ld_saved, float* stats,
+                         int act, int dact, int out_f32, int nred, const BnRedTarget* red, int dtype, void* stream) {
+    IGemmArgs a;
+    if (nt_prepare(a, x, w, y, g, N, ldw, ldy, bias, addend, ld_addend, ysaved, ld_saved, stats, act, dact, out_f32, nred, red, dtype)) return 1;
+    return nt_dispatch(a, g, N, stats, nred, dtype, (hipStream_t)stream);
+}
+
 extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom* g,
                               int N, int ldw, int ldy, const float* bias, const void* addend,
                               int ld_addend, const void* ysaved, int ld_saved, float* stats,
@@ -1012,6 +1047,39 @@ extern "C" int capmi_igemm_nt_bnred(const void* x, const void* w, void* y, const
     CAPMI_CHECK(ldy == N, "capmi_igemm_nt_bnred: output must be dense (ldy == N)");
     BnRedTarget red[2] = {{rx0, mean0, invstd0, ws0}, {rx1, mean1, invstd1, ws1}};
     return igemm_nt_impl(x, w, y, g, N, ldw, ldy, nullptr, addend, ld_addend, ysaved, ld_saved, nullptr, 0, dact, 0, nred, red, dtype, stream);
+}
+
+/* Independent NT products (disjoint outputs) issued together; see capmi.h. */
+extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count, int dtype, void* stream) {
+    CAPMI_CHECK(calls && count >= 1, "capmi_igemm_nt_group: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int first = 0; first < count; first += NT_GROUP_MAX) {
+        const int n = count - first < NT_GROUP_MAX ? count - first : NT_GROUP_MAX;
+        NtGroup grp;
+        bool fuse = dtype == CAPMI_BF16 && n > 1;
+        long long blocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const capmi_igemm_nt_call& c = calls[first + i];
+            if (nt_prepare(grp.a[i], c.x, c.w, c.y, &c.g, c.N, c.ldw, c.ldy, nullptr, c.addend, c.ld_addend, c.ysaved, c.ld_saved, nullptr,
+                           0, c.dact, 0, 0, nullptr, dtype)) return 1;
+            const IGemmArgs& a = grp.a[i];
+            fuse = fuse && !nt_uses_skinny(&c.g, a.M, a.K, false, dtype) && nt_cfg(a.M, a.N, a.K, dtype).bn == 128 && nt_cfg(a.M, a.N, a.K, dtype).wmw == 4;
+            grp.first[i] = (int)blocks;
+            blocks += ((long long)cdiv(a.M, 64) * cdiv(a.N, 128) + 7) / 8 * 8;      // ranges start at multiples of 8 (XCD order)
+        }
+        grp.first[n] = (int)blocks;
+        grp.count = n;
+        if (fuse && blocks < (1ll << 31)) {
+            hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            CAPMI_LAUNCH_CHECK("capmi_igemm_nt_group");
+        } else {
+            for (int i = 0; i < n; ++i) {
+                const capmi_igemm_nt_call& c = calls[first + i];
+                if (nt_dispatch(grp.a[i], &c.g, c.N, nullptr, 0, dtype, st)) return 1;
+            }
+        }
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------ TN kernel (weight gradient)

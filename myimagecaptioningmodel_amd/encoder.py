@@ -13,7 +13,7 @@ weight-gradient GEMM (split over pixels, f32 atomics) -> data-gradient GEMM.
 import torch
 
 from . import arch
-from ._lib import ACT_CODES, WGRAD_WS_BYTES, ConvGeom, Plan, gemm_geom, lib, wgrad_workspace
+from ._lib import ACT_CODES, WGRAD_WS_BYTES, ConvGeom, NtCall, Plan, gemm_geom, lib, wgrad_workspace
 from .params import stem_kpad
 
 BN_MOMENTUM = 0.9      # fluid.layers.batch_norm defaults; MobileNetV2.py:112-117 overrides neither
@@ -436,19 +436,18 @@ class EncoderRunner:
                                  None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code)
                     else:
                         # strided conv: one dense GEMM per output-parity class over the compact grid,
-                        # rows scattered to pixels (s*i+ph, s*j+pw) -- no MFMA on structural zeros
-                        hi, wi, _ = self.shape[op.src]
+                        # rows scattered to pixels (s*i+ph, s*j+pw) -- no MFMA on structural zeros; the
+                        # classes go out as one grouped launch
                         if not covered and addend is None:      # some pixels get no gradient: start from zero
                             plan.add('capmi_fill_f32', _p(dx), 0.0, dx.numel() * dx.element_size() // 4)
                             addend = dx
-                        for (ph, pw), (d0h, d0w, nkh, nkw) in classes.items():
-                            hc, wc = (hi - ph + op.stride - 1) // op.stride, (wi - pw + op.stride - 1) // op.stride
-                            # ho = i + d0h + r'  <=>  hn = i*1 - pad' + r' with pad' = -d0h
-                            gd = ConvGeom(B, ho, wo, op.cout, hc, wc, nkh, nkw, 1, 1, -d0h, op.cout, op.stride, ph, pw, hi, wi)
-                            if d0h != d0w:
-                                raise NotImplementedError('asymmetric parity classes')
-                            plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd((op.name + '_weights', ph, pw))), _p(dx), gd, op.cin,
-                                     nkh * nkw * op.cout, op.cin, None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code)
+                        calls = (NtCall * len(launches))()
+                        for c, (gd, wkey, Kd) in zip(calls, launches):
+                            c.x, c.w, c.y, c.g = _p(self.draw), _p(weights_bwd(wkey)), _p(dx), gd
+                            c.N, c.ldw, c.ldy = op.cin, Kd, op.cin
+                            c.addend, c.ld_addend = _p(addend), op.cin
+                            c.ysaved, c.ld_saved, c.dact = ysaved, op.cin, dact
+                        plan.add('capmi_igemm_nt_group', calls, len(launches), code)
                     written.add(t)
                     if is_last and (mask or src_act is None):
                         premasked.add(t)

@@ -70,6 +70,18 @@ def describe(name, args):
         if glds:
             return 'igemm_nt_glds_kernel<%d,%d>' % (bm, bn), 2.0 * M * N * K, nbytes
         return 'igemm_nt_kernel<%s,%d,%d>' % ('bf16' if code == BF16 else 'f32', bm, bn), 2.0 * M * N * K, nbytes
+    if name == 'capmi_igemm_nt_group':
+        calls, n, code = args[0], args[1], args[2]
+        es = 2 if code == BF16 else 4
+        flops = nbytes = 0.0
+        for c in calls[:n]:
+            g = c.g
+            M, K = g.B * g.Ho * g.Wo, g.kh * g.kw * g.Cin
+            flops += 2.0 * M * c.N * K
+            nbytes += c.N * K * es + M * c.N * es * (1 + (1 if c.addend else 0) + (1 if c.ysaved else 0))
+        g = calls[0].g
+        nbytes += g.B * g.Hi * g.Wi * g.Cin * es          # the shared input is read once
+        return 'igemm_nt_glds_group_kernel', flops, nbytes
     if name == 'capmi_bn_bwd_reduce_final':
         return 'bn_bwd_reduce_final_kernel', 0.0, args[1] * 2 * args[2] * 4
     if name == 'capmi_igemm_tn_wgrad':

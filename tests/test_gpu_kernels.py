@@ -144,8 +144,10 @@ def test_conv_fwd_dgrad_wgrad(dtype, B, C, H, W, Co, k, s, pad):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-@pytest.mark.parametrize('B,C,H,W,Co,k,pad', [(2, 16, 12, 10, 24, 3, 1), (3, 8, 9, 11, 16, 3, 1), (2, 32, 8, 8, 16, 1, 0), (2, 16, 7, 9, 8, 1, 0)])
-def test_strided_dgrad_by_parity_classes(dtype, B, C, H, W, Co, k, pad):
+@pytest.mark.parametrize('B,C,H,W,Co,k,pad', [(2, 16, 12, 10, 24, 3, 1), (3, 8, 9, 11, 16, 3, 1), (2, 32, 8, 8, 16, 1, 0), (2, 16, 7, 9, 8, 1, 0),
+                                              (2, 136, 12, 10, 72, 3, 1), (3, 72, 21, 19, 40, 3, 1)])
+@pytest.mark.parametrize('grouped', [False, True])
+def test_strided_dgrad_by_parity_classes(dtype, B, C, H, W, Co, k, pad, grouped):
     """Data gradient of a stride-2 conv as dense GEMMs per output-parity class, rows scattered to the
     strided pixels (what encoder.plan_backward launches) == the oracle's conv2d_bwd."""
     _lib, tdt, code = _env()
@@ -162,7 +164,9 @@ def test_strided_dgrad_by_parity_classes(dtype, B, C, H, W, Co, k, pad):
     base = rnd(rng.standard_normal((B, H, W, C)), dtype)          # pre-existing gradient: accumulate form
     DX = dev(base, tdt[dtype]).clone()
     offs = dgrad_class_offsets(k, s, pad)
-    for (ph, pw, rmap, qmap) in dgrad_classes(k, s, pad):
+    classes = list(dgrad_classes(k, s, pad))
+    calls = (_lib.NtCall * len(classes))()
+    for ci, (ph, pw, rmap, qmap) in enumerate(classes):
         d0h, d0w, nkh, nkw = offs[(ph, pw)]
         wc = np.zeros((C, nkh, nkw, Co))
         for a_, r in enumerate(rmap):
@@ -170,8 +174,16 @@ def test_strided_dgrad_by_parity_classes(dtype, B, C, H, W, Co, k, pad):
                 wc[:, a_, b_, :] = w[:, :, r, q].T
         hc, wcc = (H - ph + s - 1) // s, (W - pw + s - 1) // s
         gd = _lib.ConvGeom(B, Ho, Wo, Co, hc, wcc, nkh, nkw, 1, 1, -d0h, Co, s, ph, pw, H, W)
-        _lib.call('capmi_igemm_nt', p(DY), p(dev(wc, tdt[dtype])), p(DX), gd, C, nkh * nkw * Co, C, None, p(DX), C, None, 0, None, 0, 0, 0,
-                  code[dtype], stream())
+        WC = dev(wc, tdt[dtype])
+        if grouped:
+            c = calls[ci]
+            c.x, c.w, c.y, c.g = p(DY), p(WC), p(DX), gd
+            c.N, c.ldw, c.ldy, c.addend, c.ld_addend, c.ysaved, c.ld_saved, c.dact = C, nkh * nkw * Co, C, p(DX), C, None, 0, 0
+        else:
+            _lib.call('capmi_igemm_nt', p(DY), p(WC), p(DX), gd, C, nkh * nkw * Co, C, None, p(DX), C, None, 0, None, 0, 0, 0,
+                      code[dtype], stream())
+    if grouped:         # one call for all classes (a single launch when the shape qualifies)
+        _lib.call('capmi_igemm_nt_group', calls, len(classes), code[dtype], stream())
     check(host(DX), base + _nhwc(dx), dtype, name='strided dgrad (accumulate)')
 
 
