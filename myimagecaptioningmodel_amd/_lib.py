@@ -148,27 +148,103 @@ def wgrad_workspace(device):
     return _wgrad_ws[key]
 
 
+class _SideCall:
+    """A launch that may run on the plan's side stream (lane 1); calling it is calling the entry point."""
+    lane = 1
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, *args):
+        return self.fn(*args)
+
+
 class Plan:
-    """A recorded launch sequence: (function, args-without-stream).  `run(stream)` replays it on
-    a HIP stream; static shapes make the whole sequence capturable in a hipGraph."""
+    """A recorded launch sequence: (function, name, args-without-stream).  `run(stream)` replays it on
+    a HIP stream; static shapes make the whole sequence capturable in a hipGraph.
+
+    Lanes: a call added with lane=1 may run on a side stream, ordered against the main lane only by
+    the `record(key, lane)` / `wait(key, lane)` entries around it.  The recorded order is always a valid
+    sequential order, so replaying everything on one stream (side=False, or any consumer that just
+    iterates `calls`) gives the same results."""
+
+    _side = {}          # device index -> torch side stream
 
     def __init__(self):
         self.calls = []
         self._keep = []      # keeps ConvGeom structs / tensors alive
+        self.has_lanes = False
 
-    def add(self, name, *args):
+    def add(self, name, *args, lane=0):
         fn = getattr(lib(), name)
+        if lane:
+            fn = _SideCall(fn)
+            self.has_lanes = True
         self.calls.append((fn, name, args))
         self._keep.append(args)
+
+    def record(self, key, lane):
+        """Mark a point of `lane` that another lane can wait for."""
+        self.calls.append((None, 'record', (key, lane)))
+        self._keep.append(None)
+
+    def wait(self, key, lane):
+        """`lane` does not proceed before the point recorded under `key` (no-op if it was recorded in an
+        earlier run: runs end with the lanes joined)."""
+        self.calls.append((None, 'wait', (key, lane)))
+        self._keep.append(None)
 
     def extend(self, other):
         self.calls.extend(other.calls)
         self._keep.extend(other._keep)
+        self.has_lanes = self.has_lanes or other.has_lanes
 
-    def run(self, stream):
-        for fn, name, args in self.calls:
-            if fn(*args, stream) != 0:
-                raise CapmiError('%s failed: %s' % (name, last_error()))
+    def launches(self):
+        """The kernel launches only: (fn, name, args), synchronisation entries skipped."""
+        return [c for c in self.calls if c[0] is not None]
+
+    def run(self, stream, side=True):
+        lanes = side and self.has_lanes and os.environ.get('CAPMI_LANES', '1') != '0'
+        if not lanes:
+            for fn, name, args in self.calls:
+                if fn is not None and fn(*args, stream) != 0:
+                    raise CapmiError('%s failed: %s' % (name, last_error()))
+            return
+        import torch
+        main = torch.cuda.current_stream()
+        if main.cuda_stream != stream:
+            raise CapmiError('Plan.run: a plan with lanes must run on the current torch stream')
+        dev = main.device.index
+        s1 = Plan._side.get(dev)
+        if s1 is None:
+            s1 = Plan._side[dev] = torch.cuda.Stream(device=main.device)
+        prog = getattr(self, '_prog', None)
+        if prog is None or self._prog_len != len(self.calls):
+            # compiled form: (kind, a, b, lane); waits on keys recorded in an earlier run are dropped
+            prog, events = [], {}
+            for fn, name, args in self.calls:
+                if fn is None:
+                    key, lane = args
+                    if name == 'record':
+                        events[key] = torch.cuda.Event()
+                        prog.append((1, events[key], None, lane))
+                    elif key in events:
+                        prog.append((2, events[key], None, lane))
+                else:
+                    prog.append((0, fn, args, getattr(fn, 'lane', 0)))
+            self._prog, self._prog_len = prog, len(self.calls)
+        streams = (main, s1)
+        ptrs = (main.cuda_stream, s1.cuda_stream)
+        s1.wait_stream(main)                              # fork
+        for kind, a, b, lane in prog:
+            if kind == 0:
+                if a(*b, ptrs[lane]) != 0:
+                    raise CapmiError('launch failed: %s' % last_error())
+            elif kind == 1:
+                a.record(streams[lane])
+            else:
+                streams[lane].wait_event(a)
+        main.wait_stream(s1)                              # join
 
     def __len__(self):
         return len(self.calls)

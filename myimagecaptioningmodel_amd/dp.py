@@ -104,7 +104,7 @@ class OverlappedTrainer:
         for (b, e) in buckets:
             stop = len(bwd) if e == total else index_of[e]
             sub = Plan()
-            sub.calls, sub._keep = bwd.calls[start:stop], bwd._keep[start:stop]
+            sub.calls, sub._keep, sub.has_lanes = bwd.calls[start:stop], bwd._keep[start:stop], bwd.has_lanes
             segs.append((sub, (b, e), {}))
             start = stop
         assert start == len(bwd)

@@ -128,7 +128,11 @@ class EncoderRunner:
                 max_elems = max(max_elems, B * h * w * c)
             elif isinstance(op, arch.MaxPool):
                 self.pool_idx[op.dst] = z((B, h, w, c), torch.uint8)
-        self.draw = z((max_elems,)) if need_backward else None          # grad w.r.t. a conv's raw output (scratch)
+        # grad w.r.t. a conv's raw output: a ring of scratch buffers, so that the weight gradient of layer L
+        # (side lane) can still read its buffer while the main lane already produces the one of layer L-1
+        self.draws = [z((max_elems,)) for _ in range(3)] if need_backward else None
+        self.draw = self.draws[0] if need_backward else None
+        self.overlap_wgrad = True
         ws = 0
         for op in enc.ops:
             if isinstance(op, arch.ConvBN):
@@ -303,6 +307,7 @@ class EncoderRunner:
             premasked.add(t)
 
         shortcut_done = set()           # outputs of projection shortcuts whose backward already ran on the aliased gradient
+        ring_pos, ring_user = [0], [None] * len(self.draws)
         conv_of_out = {}                # tensor id -> the ConvBN whose (fused-add) output it is
         for o in self.enc.ops:
             if isinstance(o, arch.ConvBN) and id(o) not in self.skipped:
@@ -336,6 +341,14 @@ class EncoderRunner:
                 M = B * ho * wo
                 bn = self.bn[op.dst]
                 raw = self.raw[op.dst]
+                # ring slot of this layer's raw-output gradient; its previous user's weight gradient (side lane) must be done
+                slot = ring_pos[0] % len(self.draws)
+                ring_pos[0] += 1
+                draw = self.draws[slot]
+                wl = 1 if self.overlap_wgrad else 0       # lane of the weight-gradient launches
+                if wl and ring_user[slot] is not None:
+                    plan.wait(('wgrad', ring_user[slot]), 0)
+                ring_user[slot] = op.name
                 fa = self.fused_add.get(op.dst)
                 out_id = fa.dst if fa else op.dst
                 t_act = fa.act if fa else op.act
@@ -365,23 +378,32 @@ class EncoderRunner:
                         dres_acc = 1 if fa.a in written else 0
                         written.add(fa.a)
                 plan.add('capmi_bn_bwd_apply', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
-                         _p(st.view(op.name + '_bn_scale')), _p(red), _p(self.draw), 0, _p(dres), dres_acc, M, c, act, code)
+                         _p(st.view(op.name + '_bn_scale')), _p(red), _p(draw), 0, _p(dres), dres_acc, M, c, act, code)
+                if wl:
+                    plan.record(('dz', op.name), 0)
+                    plan.wait(('dz', op.name), 1)
                 dwt = st.gview(op.name + '_weights')
                 if op.src == 0:
                     g = gemm_geom(M, self.kpad)
-                    plan.add('capmi_igemm_tn_wgrad', _p(self.col), _p(self.draw), _p(dwt), g, c, c, self.kpad, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code)
+                    plan.add('capmi_igemm_tn_wgrad', _p(self.col), _p(draw), _p(dwt), g, c, c, self.kpad, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code, lane=wl)
+                    if wl:
+                        plan.record(('wgrad', op.name), 1)
                 elif op.groups > 1:
                     hi, wi, _ = self.shape[op.src]
-                    plan.add('capmi_dwconv3x3_bwd_weight', _p(self.act[op.src]), _p(self.draw), _p(dwt), B, hi, wi, c, op.stride, ho, wo, code)
+                    plan.add('capmi_dwconv3x3_bwd_weight', _p(self.act[op.src]), _p(draw), _p(dwt), B, hi, wi, c, op.stride, ho, wo, code, lane=wl)
+                    if wl:
+                        plan.record(('wgrad', op.name), 1)
                     materialize(op.src)
                     acc = 1 if op.src in written else 0
-                    plan.add('capmi_dwconv3x3_bwd_data', _p(self.draw), _p(weights(op.name + '_weights')), _p(self.grad[op.src]),
+                    plan.add('capmi_dwconv3x3_bwd_data', _p(draw), _p(weights(op.name + '_weights')), _p(self.grad[op.src]),
                              B, hi, wi, c, op.stride, ho, wo, acc, code)
                     written.add(op.src)
                 else:
                     g = self._conv_geom(op)
                     K = op.k * op.k * op.cin
-                    plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(self.draw), _p(dwt), g, c, c, K, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code)
+                    plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(draw), _p(dwt), g, c, c, K, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code, lane=wl)
+                    if wl:
+                        plan.record(('wgrad', op.name), 1)
                     t = op.src
                     dx = self.grad[t]
                     src_act = tensor_act.get(t)
@@ -423,7 +445,7 @@ class EncoderRunner:
                                            self.red_ws[q].data_ptr() + part_off * 2 * op.cin * 4]
                                 else:
                                     tg += [None, None, None, None]
-                            plan.add('capmi_igemm_nt_bnred', _p(self.draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin,
+                            plan.add('capmi_igemm_nt_bnred', _p(draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin,
                                      _p(addend), op.cin, ysaved, op.cin, dact, len(targets), *tg, code)
                             part_off += (gd.B * gd.Ho * gd.Wo + pr - 1) // pr
                         assert part_off * 2 * op.cin <= self.red_ws[0].numel()
@@ -432,7 +454,7 @@ class EncoderRunner:
                             ws_busy[q] = id(X)
                     elif op.stride == 1:
                         gd, wkey, Kd = launches[0]
-                        plan.add('capmi_igemm_nt', _p(self.draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin,
+                        plan.add('capmi_igemm_nt', _p(draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin,
                                  None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code)
                     else:
                         # strided conv: one dense GEMM per output-parity class over the compact grid,
@@ -443,7 +465,7 @@ class EncoderRunner:
                             addend = dx
                         calls = (NtCall * len(launches))()
                         for c, (gd, wkey, Kd) in zip(calls, launches):
-                            c.x, c.w, c.y, c.g = _p(self.draw), _p(weights_bwd(wkey)), _p(dx), gd
+                            c.x, c.w, c.y, c.g = _p(draw), _p(weights_bwd(wkey)), _p(dx), gd
                             c.N, c.ldw, c.ldy = op.cin, Kd, op.cin
                             c.addend, c.ld_addend = _p(addend), op.cin
                             c.ysaved, c.ld_saved, c.dact = ysaved, op.cin, dact

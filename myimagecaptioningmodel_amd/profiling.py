@@ -117,7 +117,7 @@ def time_plan(plan, stream_ptr, repeats=1):
     assert cur.cuda_stream == stream_ptr
     for _ in range(repeats):
         evs = []
-        for fn, name, args in plan.calls:
+        for fn, name, args in plan.launches():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(cur)
             rc = fn(*args, stream_ptr)

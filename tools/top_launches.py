@@ -22,13 +22,13 @@ for plan, tag in ((prog['fwd'], 'F'), (prog['bwd'], 'B')):
     for rep in range(3):
         cur = torch.cuda.current_stream()
         es = []
-        for fn, name, args in plan.calls:
+        for fn, name, args in plan.launches():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(cur); fn(*args, st); b.record(cur)
             es.append((a, b))
         torch.cuda.synchronize()
         evs.append([a.elapsed_time(b) * 1e3 for a, b in es])
-    for i, (fn, name, args) in enumerate(plan.calls):
+    for i, (fn, name, args) in enumerate(plan.launches()):
         us = min(e[i] for e in evs)
         desc = ''
         for x in args:
