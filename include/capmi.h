@@ -30,6 +30,14 @@ enum { CAPMI_ACT_NONE = 0, CAPMI_ACT_RELU = 1, CAPMI_ACT_RELU6 = 2, CAPMI_ACT_TA
 int capmi_version(void);
 const char* capmi_last_error(void);
 
+/* Lane synchronisation: device-scope events ordering two HIP streams of one device (the launch plan's
+ * main lane and the side lane that runs weight gradients).  No timing, no system-scope fence: a default
+ * hipEventRecord writes the L2 back for the host's benefit, ~6 us of idle queue each time. */
+int capmi_event_create(void** event);
+int capmi_event_destroy(void* event);
+int capmi_event_record(void* event, void* stream);
+int capmi_stream_wait_event(void* stream, void* event);
+
 /* Geometry of one implicit-GEMM convolution pass over an NHWC tensor.
  * Output pixel (b,ho,wo), tap (r,q) reads input pixel hn = ho*sd - pad + r (same for w); with
  * `up` > 1 (data-gradient of a strided conv) the tap is valid only if hn % up == 0 and reads

@@ -94,6 +94,14 @@ QUERIES = {
     'capmi_bn_bwd_ws_floats': [_i, _i, _i],
 }
 
+# lane synchronisation (no stream-last convention): name -> argument ctypes
+SYNC = {
+    'capmi_event_create': [_p],          # void** event
+    'capmi_event_destroy': [_p],
+    'capmi_event_record': [_p, _p],
+    'capmi_stream_wait_event': [_p, _p],
+}
+
 _lib = None
 
 
@@ -114,6 +122,10 @@ def lib():
             fn.argtypes = args
             fn.restype = ctypes.c_int
         for name, args in QUERIES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
+        for name, args in SYNC.items():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = ctypes.c_int
@@ -226,14 +238,17 @@ class Plan:
                 if fn is None:
                     key, lane = args
                     if name == 'record':
-                        events[key] = torch.cuda.Event()
-                        prog.append((1, events[key], None, lane))
+                        ev = ctypes.c_void_p()
+                        if lib().capmi_event_create(ctypes.byref(ev)) != 0:
+                            raise CapmiError('capmi_event_create: %s' % last_error())
+                        events[key] = ev
+                        prog.append((1, ev, None, lane))
                     elif key in events:
                         prog.append((2, events[key], None, lane))
                 else:
                     prog.append((0, fn, args, getattr(fn, 'lane', 0)))
             self._prog, self._prog_len = prog, len(self.calls)
-        streams = (main, s1)
+        L = lib()
         ptrs = (main.cuda_stream, s1.cuda_stream)
         s1.wait_stream(main)                              # fork
         for kind, a, b, lane in prog:
@@ -241,9 +256,9 @@ class Plan:
                 if a(*b, ptrs[lane]) != 0:
                     raise CapmiError('launch failed: %s' % last_error())
             elif kind == 1:
-                a.record(streams[lane])
+                L.capmi_event_record(a, ptrs[lane])
             else:
-                streams[lane].wait_event(a)
+                L.capmi_stream_wait_event(ptrs[lane], a)
         main.wait_stream(s1)                              # join
 
     def __len__(self):

@@ -12,3 +12,30 @@ extern "C" void capmi_set_error(const char* fmt, ...) {
 }
 extern "C" const char* capmi_last_error(void) { return g_err; }
 extern "C" int capmi_version(void) { return CAPMI_ABI_VERSION; }
+
+// ------------------------------------------------------------------ lane synchronisation
+// Device-scope events for ordering two HIP streams of the SAME device (plan lanes).  Created without
+// timing and without the system-scope release a default hipEventRecord performs (an L2 write-back that
+// shows up as ~6 us of idle queue per record); the data handed from lane to lane never leaves the device.
+extern "C" int capmi_event_create(void** event) {
+    CAPMI_CHECK(event, "capmi_event_create: null pointer");
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence);
+    CAPMI_CHECK(e == hipSuccess, "capmi_event_create: %s", hipGetErrorString(e));
+    *event = (void*)ev;
+    return 0;
+}
+extern "C" int capmi_event_destroy(void* event) {
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
+    return 0;
+}
+extern "C" int capmi_event_record(void* event, void* stream) {
+    hipError_t e = hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+    CAPMI_CHECK(e == hipSuccess, "capmi_event_record: %s", hipGetErrorString(e));
+    return 0;
+}
+extern "C" int capmi_stream_wait_event(void* stream, void* event) {
+    hipError_t e = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0);
+    CAPMI_CHECK(e == hipSuccess, "capmi_stream_wait_event: %s", hipGetErrorString(e));
+    return 0;
+}

@@ -32,13 +32,15 @@ def test_library_exports_every_header_symbol_with_matching_signature():
             continue
         if name == 'capmi_igemm_tn_ws_bytes':
             continue
-        sig = _lib.SIGNATURES.get(name) or _lib.QUERIES.get(name)
+        sig = _lib.SIGNATURES.get(name) or _lib.QUERIES.get(name) or _lib.SYNC.get(name)
         assert sig is not None, 'no ctypes signature for %s' % name
         arglist = [a.strip() for a in args.split(',') if a.strip() and a.strip() != 'void']
         assert len(sig) == len(arglist), (name, len(sig), len(arglist))
         for a, t in zip(arglist, sig):
             if 'capmi_conv_geom' in a:
                 exp = _lib._g
+            elif 'capmi_igemm_nt_call' in a:
+                exp = ctypes.POINTER(_lib.NtCall)
             elif '*' in a:
                 exp = ctypes.c_void_p
             elif a.startswith('int64_t'):
@@ -52,7 +54,7 @@ def test_library_exports_every_header_symbol_with_matching_signature():
             assert t is exp, (name, a)
     # and nothing bound that the header does not declare
     declared = {n for n, _ in decls}
-    assert set(_lib.SIGNATURES) | set(_lib.QUERIES) <= declared
+    assert set(_lib.SIGNATURES) | set(_lib.QUERIES) | set(_lib.SYNC) <= declared
 
 
 def test_argument_errors_are_reported_not_thrown():
@@ -232,3 +234,24 @@ def test_lod_tensor_round_trip_and_layout(tmp_path):
     assert ckpt.load_resume_state(str(tmp_path / 'log'))['epoch'] == 4
     open(str(tmp_path / 'conv9_weights'), 'wb').close()
     assert ckpt.predicate_existing(str(tmp_path), ['conv9_weights', 'missing']) == ['conv9_weights']
+
+
+def test_plan_lanes_keep_a_valid_sequential_order():
+    """Plan lanes: side-lane launches and record/wait marks are extra entries; `launches()` (what every
+    single-stream consumer replays) is the plain launch sequence, and slices keep their marks."""
+    from myimagecaptioningmodel_amd._lib import Plan
+    p = Plan()
+    p.add('capmi_fill_f32', 1, 0.0, 4)
+    p.record(('dz', 'a'), 0)
+    p.wait(('dz', 'a'), 1)
+    p.add('capmi_fill_f32', 2, 0.0, 4, lane=1)
+    p.record(('wgrad', 'a'), 1)
+    p.wait(('wgrad', 'a'), 0)
+    p.add('capmi_fill_f32', 3, 0.0, 4)
+    assert p.has_lanes and len(p) == 7 and len(p._keep) == 7
+    names = [(n, a[0]) for _, n, a in p.launches()]
+    assert names == [('capmi_fill_f32', 1), ('capmi_fill_f32', 2), ('capmi_fill_f32', 3)]
+    assert [getattr(fn, 'lane', 0) for fn, _, _ in p.launches()] == [0, 1, 0]
+    q = Plan()
+    q.extend(p)
+    assert q.has_lanes and len(q.launches()) == 3
