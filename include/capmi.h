@@ -37,6 +37,8 @@ int capmi_event_create(void** event);
 int capmi_event_destroy(void* event);
 int capmi_event_record(void* event, void* stream);
 int capmi_stream_wait_event(void* stream, void* event);
+/* Side-lane stream of the current device: priority < 0 lowest available, > 0 highest, 0 default. */
+int capmi_stream_create(void** stream, int priority);
 
 /* Geometry of one implicit-GEMM convolution pass over an NHWC tensor.
  * Output pixel (b,ho,wo), tap (r,q) reads input pixel hn = ho*sd - pad + r (same for w); with

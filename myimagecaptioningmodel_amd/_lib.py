@@ -100,6 +100,7 @@ SYNC = {
     'capmi_event_destroy': [_p],
     'capmi_event_record': [_p, _p],
     'capmi_stream_wait_event': [_p, _p],
+    'capmi_stream_create': [_p, _i],     # void** stream, priority
 }
 
 _lib = None
@@ -223,13 +224,16 @@ class Plan:
                     raise CapmiError('%s failed: %s' % (name, last_error()))
             return
         import torch
-        main = torch.cuda.current_stream()
-        if main.cuda_stream != stream:
-            raise CapmiError('Plan.run: a plan with lanes must run on the current torch stream')
-        dev = main.device.index
-        s1 = Plan._side.get(dev)
-        if s1 is None:
-            s1 = Plan._side[dev] = torch.cuda.Stream(device=main.device)
+        L = lib()
+        dev = torch.cuda.current_device()
+        side = Plan._side.get(dev)
+        if side is None:            # (stream, fork event, join event): lowest priority, it fills the main lane's gaps
+            s, e0, e1 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            prio = int(os.environ.get('CAPMI_SIDE_PRIORITY', '-1'))
+            if L.capmi_stream_create(ctypes.byref(s), prio) or L.capmi_event_create(ctypes.byref(e0)) or L.capmi_event_create(ctypes.byref(e1)):
+                raise CapmiError('side lane: %s' % last_error())
+            side = Plan._side[dev] = (s, e0, e1)
+        s1, fork_ev, join_ev = side
         prog = getattr(self, '_prog', None)
         if prog is None or self._prog_len != len(self.calls):
             # compiled form: (kind, a, b, lane); waits on keys recorded in an earlier run are dropped
@@ -248,9 +252,9 @@ class Plan:
                 else:
                     prog.append((0, fn, args, getattr(fn, 'lane', 0)))
             self._prog, self._prog_len = prog, len(self.calls)
-        L = lib()
-        ptrs = (main.cuda_stream, s1.cuda_stream)
-        s1.wait_stream(main)                              # fork
+        ptrs = (stream, s1)
+        L.capmi_event_record(fork_ev, stream)             # fork
+        L.capmi_stream_wait_event(s1, fork_ev)
         for kind, a, b, lane in prog:
             if kind == 0:
                 if a(*b, ptrs[lane]) != 0:
@@ -259,7 +263,8 @@ class Plan:
                 L.capmi_event_record(a, ptrs[lane])
             else:
                 L.capmi_stream_wait_event(ptrs[lane], a)
-        main.wait_stream(s1)                              # join
+        L.capmi_event_record(join_ev, s1)                 # join
+        L.capmi_stream_wait_event(stream, join_ev)
 
     def __len__(self):
         return len(self.calls)

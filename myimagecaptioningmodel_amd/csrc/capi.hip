@@ -39,3 +39,17 @@ extern "C" int capmi_stream_wait_event(void* stream, void* event) {
     CAPMI_CHECK(e == hipSuccess, "capmi_stream_wait_event: %s", hipGetErrorString(e));
     return 0;
 }
+
+// A stream of the current device for the side lane.  priority < 0: the lowest priority the device offers
+// (the side lane should fill the gaps of the main lane, not take compute units from it), 0: default.
+extern "C" int capmi_stream_create(void** stream, int priority) {
+    CAPMI_CHECK(stream, "capmi_stream_create: null pointer");
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    CAPMI_CHECK(e == hipSuccess, "capmi_stream_create: %s", hipGetErrorString(e));
+    hipStream_t s;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority < 0 ? least : (priority > 0 ? greatest : 0));
+    CAPMI_CHECK(e == hipSuccess, "capmi_stream_create: %s", hipGetErrorString(e));
+    *stream = (void*)s;
+    return 0;
+}
