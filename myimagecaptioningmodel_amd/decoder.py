@@ -28,6 +28,8 @@ def vocab_ld(V):
 
 class DecoderRunner:
     def __init__(self, store, B, K, T, dtype_code, torch_dtype, slots, need_backward=True):
+        self.overlap_wgrad = True       # parameter-gradient launches of the backward plan go to the side lane
+        self._sync_at = 0
         cfg = store.cfg
         self.store = store
         self.B, self.K, self.T = B, K, T
@@ -77,14 +79,27 @@ class DecoderRunner:
         plan.add('capmi_igemm_nt', x, w, y, g, N, K if ldw is None else ldw, N if ldy is None else ldy, bias, addend,
                  ld_add, ysaved, ld_saved, None, act, dact, out_f32, self.code)
 
+    def _side_ready(self, plan):
+        """Parameter-gradient launches run on the side lane (they feed nothing downstream): before one is
+        recorded, let lane 1 see everything the main lane has produced so far.  One event per burst."""
+        if not self.overlap_wgrad:
+            return 0
+        tail = plan.calls[self._sync_at:]
+        if self._sync_at == 0 or any(fn is not None and not getattr(fn, 'lane', 0) for fn, _, _ in tail):
+            key = ('dec', len(plan.calls))
+            plan.record(key, 0)
+            plan.wait(key, 1)
+            self._sync_at = len(plan.calls)
+        return 1
+
     def _wgrad(self, plan, x, rows, K, dy, N, dw, ldx=None, ldy=None, lddw=None):
         """dw[N][K] += dy[rows][N]^T . x[rows][K]"""
         g = gemm_geom(rows, K, ldx)
         plan.add('capmi_igemm_tn_wgrad', x, dy, dw, g, N, N if ldy is None else ldy, K if lddw is None else lddw,
-                 _p(wgrad_workspace(self.store.device)), WGRAD_WS_BYTES, self.code)
+                 _p(wgrad_workspace(self.store.device)), WGRAD_WS_BYTES, self.code, lane=self._side_ready(plan))
 
     def _colsum(self, plan, a, rows, N, out, lda=None):
-        plan.add('capmi_colsum', a, rows, N, N if lda is None else lda, out, self.code)
+        plan.add('capmi_colsum', a, rows, N, N if lda is None else lda, out, self.code, lane=self._side_ready(plan))
 
     def _fc(self, key):
         return FC[key] + '.w_0', FC[key] + '.b_0'
@@ -171,6 +186,7 @@ class DecoderRunner:
         accumulates every decoder parameter gradient into the store's flat gradient buffer."""
         st, B, K, T, C, H, E, V, Vld = self.store, self.B, self.K, self.T, self.C, self.H, self.E, self.V, self.Vld
         M, code = T * B, self.code
+        self._sync_at = 0
         es = self.X.element_size()
         g_ = lambda n: _p(st.gview(n))
         w0, b0 = self._fc('img_embed')
@@ -191,6 +207,8 @@ class DecoderRunner:
         # tied projection (:25): d bias, d Emb (dense part, quirk Q6), d proj
         self._colsum(plan, _p(self.dlogits), M, V, g_('out_fc_bias'), lda=Vld)
         self._wgrad(plan, _p(self.R), M, E, _p(self.dlogits), V, g_('word_embedding'), ldy=Vld)
+        if self.overlap_wgrad:
+            plan.record(('dec', 'tied projection'), 1)      # embedding_bwd adds into the same rows (ordered below)
         self._gemm(plan, _p(self.dlogits), M, Vld, _p(WT('word_embedding')), E, _p(self.dR), ldw=Vld)
         # fc_12 (:24) and fc_11 + tanh (:115)
         self._wgrad(plan, _p(self.O), M, H, _p(self.dR), E, g_(w12))
@@ -246,6 +264,8 @@ class DecoderRunner:
         self._colsum(plan, _p(self.dG), M, 4 * H, g_('lstm_b'))
         self._gemm(plan, _p(self.dG), M, 4 * H, _p(lwT), E + H, _p(self.dX), addend=_p(self.dX), ld_add=E + H)
         # x_t = [emb ; g] (:84-86)
+        if self.overlap_wgrad:
+            plan.wait(('dec', 'tied projection'), 0)
         plan.add('capmi_embedding_bwd', _p(self.ids), _p(self.dX), g_('word_embedding'), M, E, V, E + H, self.pad, code)
         plan.add('capmi_bcast_rows_bwd', _p(self.dX), _p(self.dg), T, B, H, E + H, E, code)
         # pre-loop projections (:52-53)
