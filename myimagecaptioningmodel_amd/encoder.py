@@ -133,12 +133,14 @@ class EncoderRunner:
         self.draws = [z((max_elems,)) for _ in range(3)] if need_backward else None
         self.draw = self.draws[0] if need_backward else None
         self.overlap_wgrad = True
+        self.draw_side = z((max_elems,)) if need_backward else None     # raw-output gradient of a projection shortcut (side lane)
         ws = 0
         for op in enc.ops:
             if isinstance(op, arch.ConvBN):
                 h, w, c = self.shape[op.dst]
                 ws = max(ws, lib().capmi_bn_bwd_ws_floats(B * h * w, c, dtype_code))
         self.bwd_ws = z((ws,), torch.float32) if need_backward else None  # partial sums of bn_bwd_reduce (scratch)
+        self.bwd_ws_side = z((ws,), torch.float32) if need_backward else None
         # partial sums written by data-gradient epilogues (capmi_igemm_nt_bnred): <= one part per 64 rows (+ class tails)
         red_floats = max([(((B * self.shape[op.dst][0] * self.shape[op.dst][1] + 63) // 64) + 8) * 2 * self.shape[op.dst][2]
                           for op in enc.ops if isinstance(op, arch.ConvBN)] or [0])
@@ -308,6 +310,7 @@ class EncoderRunner:
 
         shortcut_done = set()           # outputs of projection shortcuts whose backward already ran on the aliased gradient
         ring_pos, ring_user = [0], [None] * len(self.draws)
+        side_written = {}               # tensor -> event key: its gradient's first writer ran on the side lane
         conv_of_out = {}                # tensor id -> the ConvBN whose (fused-add) output it is
         for o in self.enc.ops:
             if isinstance(o, arch.ConvBN) and id(o) not in self.skipped:
@@ -337,18 +340,27 @@ class EncoderRunner:
                     pending[op.dst] = grad_buf(blk_out)
                     premasked.add(op.dst)
                     shortcut_done.add(op.dst)
+                # a projection shortcut's whole backward (BN backward, both gradients) is independent of the
+                # branch2c..2a chain: it runs on the side lane, between two events
+                ln = 1 if (id(op) in early and self.overlap_wgrad) else 0
+                if ln:
+                    plan.record(('blk', op.name), 0)
+                    plan.wait(('blk', op.name), 1)
                 ho, wo, c = self.shape[op.dst]
                 M = B * ho * wo
                 bn = self.bn[op.dst]
                 raw = self.raw[op.dst]
                 # ring slot of this layer's raw-output gradient; its previous user's weight gradient (side lane) must be done
-                slot = ring_pos[0] % len(self.draws)
-                ring_pos[0] += 1
-                draw = self.draws[slot]
                 wl = 1 if self.overlap_wgrad else 0       # lane of the weight-gradient launches
-                if wl and ring_user[slot] is not None:
-                    plan.wait(('wgrad', ring_user[slot]), 0)
-                ring_user[slot] = op.name
+                if ln:
+                    draw = self.draw_side
+                else:
+                    slot = ring_pos[0] % len(self.draws)
+                    ring_pos[0] += 1
+                    draw = self.draws[slot]
+                    if wl and ring_user[slot] is not None:
+                        plan.wait(('wgrad', ring_user[slot]), 0)
+                    ring_user[slot] = op.name
                 fa = self.fused_add.get(op.dst)
                 out_id = fa.dst if fa else op.dst
                 t_act = fa.act if fa else op.act
@@ -363,7 +375,7 @@ class EncoderRunner:
                     plan.add('capmi_bn_bwd_reduce_final', _p(self.red_ws[slot]), parts, c, _p(red))
                     ws_busy[slot] = None
                 else:
-                    plan.add('capmi_bn_bwd_reduce', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']), _p(self.bwd_ws), _p(red), M, c, act, code)
+                    plan.add('capmi_bn_bwd_reduce', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']), _p(self.bwd_ws_side if ln else self.bwd_ws), _p(red), M, c, act, code, lane=ln)
                 dres, dres_acc = None, 0
                 if fa is not None and fa.a in shortcut_done:
                     pending.pop(fa.a, None)
@@ -378,20 +390,20 @@ class EncoderRunner:
                         dres_acc = 1 if fa.a in written else 0
                         written.add(fa.a)
                 plan.add('capmi_bn_bwd_apply', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
-                         _p(st.view(op.name + '_bn_scale')), _p(red), _p(draw), 0, _p(dres), dres_acc, M, c, act, code)
-                if wl:
+                         _p(st.view(op.name + '_bn_scale')), _p(red), _p(draw), 0, _p(dres), dres_acc, M, c, act, code, lane=ln)
+                if wl and not ln:
                     plan.record(('dz', op.name), 0)
                     plan.wait(('dz', op.name), 1)
                 dwt = st.gview(op.name + '_weights')
                 if op.src == 0:
                     g = gemm_geom(M, self.kpad)
                     plan.add('capmi_igemm_tn_wgrad', _p(self.col), _p(draw), _p(dwt), g, c, c, self.kpad, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code, lane=wl)
-                    if wl:
+                    if wl and not ln:
                         plan.record(('wgrad', op.name), 1)
                 elif op.groups > 1:
                     hi, wi, _ = self.shape[op.src]
                     plan.add('capmi_dwconv3x3_bwd_weight', _p(self.act[op.src]), _p(draw), _p(dwt), B, hi, wi, c, op.stride, ho, wo, code, lane=wl)
-                    if wl:
+                    if wl and not ln:
                         plan.record(('wgrad', op.name), 1)
                     materialize(op.src)
                     acc = 1 if op.src in written else 0
@@ -402,7 +414,7 @@ class EncoderRunner:
                     g = self._conv_geom(op)
                     K = op.k * op.k * op.cin
                     plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(draw), _p(dwt), g, c, c, K, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code, lane=wl)
-                    if wl:
+                    if wl and not ln:
                         plan.record(('wgrad', op.name), 1)
                     t = op.src
                     dx = self.grad[t]
@@ -412,6 +424,8 @@ class EncoderRunner:
                     covered = classes is None or len(classes) == op.stride * op.stride
                     if not covered:
                         materialize(t)          # pixels outside the classes keep their earlier contribution
+                    if not ln and t in side_written:     # the side lane wrote grad[t] first: wait for it
+                        plan.wait(side_written.pop(t), 0)
                     addend = dx if t in written else pending.pop(t, None)
                     mask = is_last and covered and src_act is not None
                     ysaved, dact = (_p(self.act[t]), ACT_CODES[src_act]) if mask else (None, 0)
@@ -455,22 +469,25 @@ class EncoderRunner:
                     elif op.stride == 1:
                         gd, wkey, Kd = launches[0]
                         plan.add('capmi_igemm_nt', _p(draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin,
-                                 None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code)
+                                 None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code, lane=ln)
                     else:
                         # strided conv: one dense GEMM per output-parity class over the compact grid,
                         # rows scattered to pixels (s*i+ph, s*j+pw) -- no MFMA on structural zeros; the
                         # classes go out as one grouped launch
                         if not covered and addend is None:      # some pixels get no gradient: start from zero
-                            plan.add('capmi_fill_f32', _p(dx), 0.0, dx.numel() * dx.element_size() // 4)
+                            plan.add('capmi_fill_f32', _p(dx), 0.0, dx.numel() * dx.element_size() // 4, lane=ln)
                             addend = dx
                         calls = (NtCall * len(launches))()
-                        for c, (gd, wkey, Kd) in zip(calls, launches):
-                            c.x, c.w, c.y, c.g = _p(draw), _p(weights_bwd(wkey)), _p(dx), gd
-                            c.N, c.ldw, c.ldy = op.cin, Kd, op.cin
-                            c.addend, c.ld_addend = _p(addend), op.cin
-                            c.ysaved, c.ld_saved, c.dact = ysaved, op.cin, dact
-                        plan.add('capmi_igemm_nt_group', calls, len(launches), code)
+                        for cl, (gd, wkey, Kd) in zip(calls, launches):
+                            cl.x, cl.w, cl.y, cl.g = _p(draw), _p(weights_bwd(wkey)), _p(dx), gd
+                            cl.N, cl.ldw, cl.ldy = op.cin, Kd, op.cin
+                            cl.addend, cl.ld_addend = _p(addend), op.cin
+                            cl.ysaved, cl.ld_saved, cl.dact = ysaved, op.cin, dact
+                        plan.add('capmi_igemm_nt_group', calls, len(launches), code, lane=ln)
                     written.add(t)
+                    if ln:
+                        plan.record(('pdone', op.name), 1)
+                        side_written[t] = ('pdone', op.name)
                     if is_last and (mask or src_act is None):
                         premasked.add(t)
             elif isinstance(op, arch.Add):
