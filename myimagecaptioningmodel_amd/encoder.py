@@ -133,6 +133,7 @@ class EncoderRunner:
         self.draws = [z((max_elems,)) for _ in range(3)] if need_backward else None
         self.draw = self.draws[0] if need_backward else None
         self.overlap_wgrad = True
+        self.overlap_forward = True     # projection shortcuts of the forward pass on the side lane
         self.draw_side = z((max_elems,)) if need_backward else None     # raw-output gradient of a projection shortcut (side lane)
         ws = 0
         for op in enc.ops:
@@ -178,10 +179,25 @@ class EncoderRunner:
         """image: f32 NCHW [B,3,S,S] device tensor (the reference feed).  weights(name) -> tensor
         the kernels read (f32 master or bf16 shadow)."""
         st, B, code = self.store, self.B, self.code
+        # a projection shortcut (conv + BN whose output only feeds a fused add) is independent of the
+        # branch2a..2c chain of its block: side lane, joined before the bn_apply that adds it
+        side_ops, side_out = set(), set()
+        if self.overlap_forward:
+            producer = {o.dst: o for o in self.enc.ops}
+            for o in self.enc.ops:
+                fa = self.fused_add.get(o.dst) if isinstance(o, arch.ConvBN) else None
+                p = producer.get(fa.a) if fa is not None else None
+                if isinstance(p, arch.ConvBN) and p.act is None and p.dst not in self.fused_add and self._consumers.get(p.dst, 0) == 1 \
+                        and p.src != 0 and p.groups == 1:
+                    side_ops.add(id(p))
         for op in self.enc.ops:
             if id(op) in self.skipped:
                 continue
             if isinstance(op, arch.ConvBN):
+                ln = 1 if id(op) in side_ops else 0
+                if ln:
+                    plan.record(('fin', op.name), 0)
+                    plan.wait(('fin', op.name), 1)
                 ho, wo, c = self.shape[op.dst]
                 M = B * ho * wo
                 bn = self.bn[op.dst]
@@ -201,16 +217,21 @@ class EncoderRunner:
                     g = self._conv_geom(op)
                     K = op.k * op.k * op.cin
                     plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
-                             _p(bn['stats']), 0, 0, 0, code)
+                             _p(bn['stats']), 0, 0, 0, code, lane=ln)
                 plan.add('capmi_bn_finalize', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')),
                          _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS,
-                         _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0)
+                         _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, lane=ln)
                 offset = _p(st.view(op.name + '_bn_offset'))
                 fa = self.fused_add.get(op.dst)
                 if fa is None:
                     plan.add('capmi_bn_apply', _p(raw), _p(bn['mean']), _p(bn['a']), offset, None, _p(self.act[op.dst]), M, c,
-                             ACT_CODES[op.act], code)
+                             ACT_CODES[op.act], code, lane=ln)
+                    if ln:
+                        plan.record(('fout', op.dst), 1)
+                        side_out.add(op.dst)
                 else:
+                    if fa.a in side_out:
+                        plan.wait(('fout', fa.a), 0)
                     plan.add('capmi_bn_apply', _p(raw), _p(bn['mean']), _p(bn['a']), offset, _p(self.act[fa.a]), _p(self.act[fa.dst]),
                              M, c, ACT_CODES[fa.act], code)
             elif isinstance(op, arch.Add):
