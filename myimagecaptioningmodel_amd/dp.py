@@ -123,7 +123,7 @@ class OverlappedTrainer:
             eng.refresh_shadows()
         eng._feed_train(prog, image, caption)
         cur = torch.cuda.current_stream(eng.device)
-        eng._run_captured(P['fwd_graph'], 'g', [prog['fwd']])
+        eng._run_captured(P['fwd_graph'], 'g', prog['fwd_parts'] if eng.graph_decoder_forward else [prog['fwd']])
         grad = eng.store.grad
         for sub, (b, e), holder in P['segs']:
             eng._run_captured(holder, 'g', [sub])
