@@ -914,6 +914,7 @@ static NtCfg nt_cfg(int M, int N, int K, int dtype) {
             if (!big && (int64_t)cdiv(M, 64) * cdiv(N, 128) < 256) return NtCfg{64, 64, 5};      // under-filled grid: 64x64 LDS-DMA tiles (wmw 5 = marker)
             return NtCfg{big ? 128 : 64, 128, 4};
         }
+        if (N >= 32) return NtCfg{64, 64, 5};          // LDS-DMA 64x64 tiles
         const bool tall = cdiv(M, 128) >= 512;
         return NtCfg{tall ? 128 : 64, 64, 4};
     }

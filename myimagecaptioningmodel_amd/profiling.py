@@ -34,6 +34,8 @@ def _nt_tile(M, N, K, bf16):
             if not big and cd(M, 64) * cd(N, 128) < 256:
                 return (64, 64, True)
             return (128 if big else 64, 128, True)
+        if N >= 32:
+            return (64, 64, True)
         return (128 if cd(M, 128) >= 512 else 64, 64, False)
     tall = cd(M, 128) * cd(N, 64) >= 256
     return (64, 128, False) if wide else ((128 if tall else 64), 64, False)
