@@ -58,6 +58,7 @@ class CaptionEngine:
         self.store.init_reference(seed=cfg.get('seed') or 0)
         self.use_graph = use_graph
         self.graph_decoder_forward = False
+        self.fuse_optimizer = True      # single rank: Adam + shadow refresh inside the backward plan (side lane)
         self.overlap_lanes = True       # laned plans (side-stream weight gradients) run eagerly on two HIP streams
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
@@ -123,6 +124,7 @@ class CaptionEngine:
         for i, j in enumerate(jobs):
             table[i] = j
         self.dgrad_jobs = torch.from_numpy(table.view(np.uint8)).to(self.device)
+        self.dgrad_job_src = [j[0] for j in jobs]           # flat offsets of the jobs' source weights (non-decreasing)
         self.shadow_plan.add('capmi_weight_dgrad_form_batched', _p(st.flat), _p(self.wT), _p(self.dgrad_jobs), len(jobs), self.code)
 
     def W(self, name):
@@ -303,8 +305,80 @@ class CaptionEngine:
         if self.world > 1:
             torch.distributed.all_reduce(self.store.grad[:self.store.trainable_size], group=self.pg)
 
+    def _build_fused_bwd(self, prog):
+        """Backward plan with the optimizer inside (single-rank training): once ~90 % of the parameters have
+        their final gradients, Adam + the shadow refresh of that range run on the side lane under the rest
+        of the backward pass; only the small remainder is updated after the last weight gradient."""
+        import ctypes
+        st, bwd, cfg = self.store, prog['bwd'], self.cfg
+        total = st.trainable_size
+        cut_idx, cut = None, total
+        for idx, opname in prog['marks']:
+            e = st.entries[opname + '_bn_scale']
+            off = e.offset + (int(e.kshape[0]) + 7) // 8 * 8
+            if off >= 0.9 * total and off < total:
+                cut_idx, cut = idx, off
+                break
+        lrt = ctypes.c_float(0.0)
+        clip = float(cfg['gradient_clip']) if cfg.get('gradient_clip') else 0.0
+        es4 = 4
+
+        def optimizer_range(plan, b, e, lane):
+            if e <= b:
+                return
+            plan.add('capmi_adam', st.flat.data_ptr() + b * es4, st.grad.data_ptr() + b * es4, st.adam_m.data_ptr() + b * es4,
+                     st.adam_v.data_ptr() + b * es4, e - b, lrt, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, 1.0, lane=lane)
+
+        def shadow_range(plan, b, e, lane):
+            if self.low is not None and e > b:
+                plan.add('capmi_cast', st.flat.data_ptr() + b * es4, self.low.data_ptr() + b * self.low.element_size(), e - b, self.code, lane=lane)
+            j0 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= b), len(self.dgrad_job_src))
+            j1 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= e), len(self.dgrad_job_src))
+            if j1 > j0:
+                plan.add('capmi_weight_dgrad_form_batched', _p(st.flat), _p(self.wT), self.dgrad_jobs.data_ptr() + j0 * 56, j1 - j0, self.code, lane=lane)
+
+        fused = Plan()
+        head = Plan()
+        head.calls, head._keep, head.has_lanes = bwd.calls[:cut_idx or 0], bwd._keep[:cut_idx or 0], bwd.has_lanes
+        tail = Plan()
+        tail.calls, tail._keep, tail.has_lanes = bwd.calls[cut_idx or 0:], bwd._keep[cut_idx or 0:], bwd.has_lanes
+        fused.extend(head)
+        if cut_idx is not None and bwd.has_lanes:
+            fused.record(('opt', 'head'), 0)
+            fused.wait(('opt', 'head'), 1)
+            optimizer_range(fused, 0, cut, 1)
+            shadow_range(fused, 0, cut, 1)
+        else:
+            cut = 0
+        fused.extend(tail)
+        if bwd.has_lanes:
+            fused.record(('opt', 'tail'), 1)            # the last weight gradient (side lane) is done
+            fused.wait(('opt', 'tail'), 0)
+        optimizer_range(fused, cut, total, 0)
+        shadow_range(fused, cut, st.size, 0)
+        prog['bwd_opt'], prog['lrt'] = fused, lrt
+        return fused
+
     def train_step(self, image, caption):
         """feed -> fwd -> bwd -> (all-reduce) -> Adam; returns (loss tensor [1], lr float)."""
+        lanes_on = self.overlap_lanes and os.environ.get('CAPMI_LANES', '1') != '0'
+        # (a captured graph would freeze this step's learning rate: the fused plan is only ever launched eagerly)
+        if self.world == 1 and self.fuse_optimizer and self.cfg['encoder_trainable'] and (lanes_on or not self.use_graph):
+            B = int(image.shape[0])
+            prog = self._train.get(B)
+            if prog is None:
+                prog = self._train[B] = self._compile_train(B)
+            if self.shadows_dirty:
+                self.refresh_shadows()
+            if 'bwd_opt' not in prog:
+                self._build_fused_bwd(prog)
+            self._feed_train(prog, image, caption)
+            lr = self.lr_schedule.value(self.step_count)
+            self.step_count += 1
+            prog['lrt'].value = adam_lr_t(lr, self.step_count)
+            fwd = prog['fwd_parts'] if self.graph_decoder_forward else [prog['fwd']]
+            self._run_captured(prog, 'graph_opt', fwd + [prog['bwd_opt']])
+            return prog['dec'].loss, lr
         loss = self.forward_backward(image, caption)
         self.allreduce_grads()
         lr = self.optimizer_step()
