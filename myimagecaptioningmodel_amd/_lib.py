@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcapmi.so')
+LIB_PATH = os.environ.get('CAPMI_LIB') or os.path.join(_HERE, 'libcapmi.so')
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4

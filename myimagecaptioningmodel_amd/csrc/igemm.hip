@@ -1373,16 +1373,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
-// Splits over the reduction (pixel) axis: as many as fit in ONE round of resident workgroups (3 per CU
-// for the 128x128 LDS-DMA kernel, 4 for the 64x64 one) -- one workgroup more than that costs a whole
-// second round --, every split >= 256 rows deep, and the partial slabs (tiles x splits x tile elements)
-// capped at 6 M floats (24 MB: ~4 us to store, ~5 us to read back).
+// Splits over the reduction (pixel) axis: at most ONE workgroup per CU for the 128x128 LDS-DMA kernel (two
+// for the 64x64 one).  Weight gradients run on the side lane under the BN-backward / data-gradient chain,
+// which has twice their work: fewer, longer workgroups leave compute units and L2 to the main lane
+// (+1 % per step over filling every resident slot) and write fewer slab partials.  Never one workgroup more
+// than a full round (that costs a whole second round); every split >= 256 rows deep; slabs capped at
+// 6 M floats (24 MB: ~4 us to store, ~5 us to read back).
 static int tn_splits(int M, int N, int K, int bno, int bko, int* per_out) {
     const int tiles = cdiv(N, bno) * cdiv(K, bko);
     const long long out_elems = (long long)cdiv(N, bno) * bno * cdiv(K, bko) * bko;
     long long by_ws = (6ll << 20) / (out_elems > 0 ? out_elems : 1);
     if (by_ws < 1) by_ws = 1;
-    const int slots = 256 * (bno >= 128 ? 3 : 4);
+    const int slots = 256 * (bno >= 128 ? 1 : 2);
     int want = slots / tiles;
     int max_splits = cdiv(M, 256);
     if (max_splits > by_ws) max_splits = (int)by_ws;
