@@ -123,6 +123,16 @@ int capmi_colsum(const void* a, int M, int N, int lda, float* out, int dtype, vo
  * patch matrix in `dtype`, k=(r,q,c), zero padded to Kpad. */
 int capmi_im2col_stem(const float* img, void* out, int B, int C, int H, int W, int k, int stride,
                       int pad, int Ho, int Wo, int Kpad, int dtype, void* stream);
+/* The stem without a patch matrix: 2x2 space-to-depth of the zero-padded NCHW f32 feed,
+ * out[b][bh][bw][(ph*2+pw)*C + c] = img[b][c][2bh+ph-pad][2bw+pw-pad] (0 outside, channels 4C..Cs zero),
+ * on which a k x k / stride-2 / pad convolution is a ceil(k/2)^2 / stride-1 / unpadded one with the filter
+ * Ws[n][r'][q'][(ph*2+pw)*C + c] = W[n][c][2r'+ph][2q'+pw] (0 where 2r'+ph >= k or 2q'+pw >= k):
+ * run it with capmi_igemm_nt / capmi_igemm_tn_wgrad like any other conv (Hb = Ho + (k-1)/2).
+ * capmi_s2d_stem_mask_grad zeroes the filter-gradient slots of those structural zeros.
+ * Replaces conv2d on the image feed (MobileNetV2.py:28-36 / the build-defined ResNet stem). */
+int capmi_s2d_stem(const float* img, void* out, int B, int C, int H, int W, int pad, int Hb, int Wb, int Cs,
+                   int dtype, void* stream);
+int capmi_s2d_stem_mask_grad(float* dw, int Cout, int C, int k, int Cs, void* stream);
 
 /* Depthwise 3x3 (fluid.layers.conv2d groups=C use_cudnn=False, IC/model/MobileNetV2.py:155-164).
  * w is [3][3][C] f32/bf16 as `dtype`; dw is f32 [3][3][C] (atomic accumulate). */

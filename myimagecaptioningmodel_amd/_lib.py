@@ -44,6 +44,8 @@ SIGNATURES = {
     'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
     'capmi_colsum': [_p, _i, _i, _i, _p, _i, _p],
     'capmi_im2col_stem': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_s2d_stem': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_s2d_stem_mask_grad': [_p, _i, _i, _i, _i, _p],
     'capmi_dwconv3x3_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_dwconv3x3_bwd_data': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_dwconv3x3_bwd_weight': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],

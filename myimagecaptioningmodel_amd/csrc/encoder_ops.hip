@@ -151,6 +151,67 @@ extern "C" int capmi_im2col_stem(const float* img, void* out, int B, int C, int 
     return 0;
 }
 
+// ------------------------------------------------------------------ stem as space-to-depth (no patch matrix)
+// A k x k / stride-2 convolution on the 3-channel feed equals a ceil(k/2) x ceil(k/2) / stride-1 convolution
+// on the 2x2 space-to-depth image of the zero-padded feed: tap r = 2r' + ph of input row 2ho - pad + r is
+// tap r' of block row ho + r', sub-row ph.  The blocks are written NHWC with channel (ph*2 + pw)*C + c,
+// padded to Cs channels: [B][Hb][Wb][Cs], 27 MB at B = 64 instead of a 257 MB im2col matrix that the
+// forward GEMM and the weight gradient would each read again; the stem then is an ordinary implicit GEMM.
+template <typename T>
+__global__ __launch_bounds__(256) void s2d_stem_kernel(const float* __restrict__ img, T* out, int B, int C, int H, int W, int pad,
+                                                       int Hb, int Wb, int Cs) {
+    const int64_t n = (int64_t)B * Hb * Wb;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int bw = (int)(e % Wb), bh = (int)((e / Wb) % Hb);
+        const int64_t b = e / ((int64_t)Wb * Hb);
+        T* o = out + e * Cs;
+        constexpr int VEC = Vec<T>::N;
+        for (int c0 = 0; c0 < Cs; c0 += VEC) {
+            Vec<T> ov;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int ch = c0 + v;
+                float f = 0.f;
+                if (ch < 4 * C) {
+                    const int c = ch % C, sub = ch / C, ph = sub >> 1, pw = sub & 1;
+                    const int h = 2 * bh + ph - pad, w = 2 * bw + pw - pad;
+                    if (h >= 0 && h < H && w >= 0 && w < W) f = img[((b * C + c) * H + h) * W + w];
+                }
+                ov.set(v, f);
+            }
+            vstore<T>(o + c0, ov);
+        }
+    }
+}
+extern "C" int capmi_s2d_stem(const float* img, void* out, int B, int C, int H, int W, int pad, int Hb, int Wb, int Cs,
+                              int dtype, void* stream) {
+    CAPMI_CHECK(img && out, "capmi_s2d_stem: null pointer");
+    CAPMI_CHECK(Cs >= 4 * C && Cs % 8 == 0, "capmi_s2d_stem: Cs=%d must be a multiple of 8 and >= 4*C", Cs);
+    CAPMI_DISPATCH(dtype, "capmi_s2d_stem", {
+        hipLaunchKernelGGL(s2d_stem_kernel<T>, dim3(ew_grid((int64_t)B * Hb * Wb)), dim3(256), 0, (hipStream_t)stream, img, (T*)out, B, C, H, W,
+                           pad, Hb, Wb, Cs);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_s2d_stem");
+    return 0;
+}
+// Filter-gradient slots of the space-to-depth form that no filter tap maps to (r = 2r'+ph >= k, the padding
+// channels) pick up data products: zero them so that Adam leaves the structural zeros of the filter alone.
+__global__ __launch_bounds__(256) void s2d_stem_mask_kernel(float* dw, int Cout, int C, int k, int kt, int Cs) {
+    const int per = kt * kt * Cs, n = Cout * per;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        const int ch = e % Cs, q2 = (e / Cs) % kt, r2 = (e / (Cs * kt)) % kt;
+        const int sub = ch / C, ph = sub >> 1, pw = sub & 1;
+        if (ch >= 4 * C || 2 * r2 + ph >= k || 2 * q2 + pw >= k) dw[e] = 0.f;
+    }
+}
+extern "C" int capmi_s2d_stem_mask_grad(float* dw, int Cout, int C, int k, int Cs, void* stream) {
+    CAPMI_CHECK(dw, "capmi_s2d_stem_mask_grad: null pointer");
+    const int kt = (k + 1) / 2;
+    hipLaunchKernelGGL(s2d_stem_mask_kernel, dim3(cdiv(Cout * kt * kt * Cs, 256)), dim3(256), 0, (hipStream_t)stream, dw, Cout, C, k, kt, Cs);
+    CAPMI_LAUNCH_CHECK("capmi_s2d_stem_mask_grad");
+    return 0;
+}
+
 // ------------------------------------------------------------------ depthwise 3x3
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const T* __restrict__ w, T* y, int B, int Hi, int Wi,

@@ -14,7 +14,7 @@ import torch
 
 from . import arch
 from ._lib import ACT_CODES, WGRAD_WS_BYTES, ConvGeom, NtCall, Plan, gemm_geom, lib, wgrad_workspace
-from .params import stem_kpad
+from .params import stem_s2d
 
 BN_MOMENTUM = 0.9      # fluid.layers.batch_norm defaults; MobileNetV2.py:112-117 overrides neither
 BN_EPS = 1e-5
@@ -148,14 +148,22 @@ class EncoderRunner:
         self.red_ws = [z((red_floats,), torch.float32), z((red_floats,), torch.float32)] if need_backward else None
         stem = enc.ops[0]
         h, w, _ = self.shape[stem.dst]
-        self.kpad = stem_kpad(stem.k, stem.cin)
-        self.col = z((B * h * w, self.kpad))
+        assert stem.stride == 2 and stem.src == 0, 'the stem is a stride-2 convolution on the image feed'
+        # space-to-depth image of the padded feed: the stem becomes a stride-1 implicit GEMM on it (capmi_s2d_stem)
+        self.stem_kt, self.stem_cs = stem_s2d(stem.k, stem.cin)
+        self.stem_hb, self.stem_wb = h + (stem.k - 1) // 2, w + (stem.k - 1) // 2
+        self.s2d = z((B, self.stem_hb, self.stem_wb, self.stem_cs))
         self.out_id = enc.out
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
     def kpad_of(op):
-        return stem_kpad(op.k, op.cin)
+        kt, cs = stem_s2d(op.k, op.cin)
+        return kt * kt * cs
+
+    def _stem_geom(self, op):
+        ho, wo, _ = self.shape[op.dst]
+        return ConvGeom(self.B, self.stem_hb, self.stem_wb, self.stem_cs, ho, wo, self.stem_kt, self.stem_kt, 1, 1, 0, self.stem_cs)
 
     def _conv_geom(self, op):
         hi, wi, _ = self.shape[op.src]
@@ -203,11 +211,10 @@ class EncoderRunner:
                 bn = self.bn[op.dst]
                 raw = self.raw[op.dst]
                 w = weights(op.name + '_weights')
-                if op.src == 0:        # stem: explicit im2col of the NCHW feed, then a plain GEMM
-                    plan.add('capmi_im2col_stem', _p(image), _p(self.col), B, op.cin, self.S, self.S, op.k, op.stride,
-                             op.pad, ho, wo, self.kpad, code)
-                    g = gemm_geom(M, self.kpad)
-                    plan.add('capmi_igemm_nt', _p(self.col), _p(w), _p(raw), g, c, self.kpad, c, None, None, 0, None, 0,
+                if op.src == 0:        # stem: space-to-depth of the NCHW feed, then an ordinary stride-1 implicit GEMM
+                    plan.add('capmi_s2d_stem', _p(image), _p(self.s2d), B, op.cin, self.S, self.S, op.pad, self.stem_hb, self.stem_wb,
+                             self.stem_cs, code)
+                    plan.add('capmi_igemm_nt', _p(self.s2d), _p(w), _p(raw), self._stem_geom(op), c, self.kpad_of(op), c, None, None, 0, None, 0,
                              _p(bn['stats']), 0, 0, 0, code)
                 elif op.groups > 1:
                     hi, wi, _ = self.shape[op.src]
@@ -417,8 +424,9 @@ class EncoderRunner:
                     plan.wait(('dz', op.name), 1)
                 dwt = st.gview(op.name + '_weights')
                 if op.src == 0:
-                    g = gemm_geom(M, self.kpad)
-                    plan.add('capmi_igemm_tn_wgrad', _p(self.col), _p(draw), _p(dwt), g, c, c, self.kpad, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code, lane=wl)
+                    plan.add('capmi_igemm_tn_wgrad', _p(self.s2d), _p(draw), _p(dwt), self._stem_geom(op), c, c, self.kpad_of(op),
+                             _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code, lane=wl)
+                    plan.add('capmi_s2d_stem_mask_grad', _p(dwt), c, op.cin, op.k, self.stem_cs, lane=wl)
                     if wl and not ln:
                         plan.record(('wgrad', op.name), 1)
                 elif op.groups > 1:

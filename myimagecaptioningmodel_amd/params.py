@@ -6,7 +6,7 @@ Names and reference layouts follow the reference checkpoint (SURVEY.md section 5
 model_adaAttention_aic.py:16-23,29-32,87-88 and the `fc_<n>` auto-names in creation order).
 Inside the flat buffer each tensor is stored in the KERNEL layout the gfx950 kernels read:
 
-    conv filter  [Cout, Cin, kh, kw]  ->  [Cout, kh, kw, Cin]   (stem: [Cout, Kpad], zero padded)
+    conv filter  [Cout, Cin, kh, kw]  ->  [Cout, kh, kw, Cin]   (stem: space-to-depth form [Cout, kt, kt, Cs])
     depthwise    [C, 1, 3, 3]         ->  [3, 3, C]
     fc weight    [in, out]            ->  [out, in]
     lstm_w       [(E+H)+H, 4H]        ->  [4H, (E+H)+H]
@@ -36,8 +36,9 @@ FC = dict(img_embed='fc_0', img_global='fc_1', img_feat='fc_2', img_feat_emb='fc
           alpha='fc_10', out='fc_11', proj='fc_12')
 
 
-def stem_kpad(k, cin):
-    return (k * k * cin + 31) // 32 * 32
+def stem_s2d(k, cin):
+    """(taps per axis, channels) of the space-to-depth form of the k x k / stride-2 stem (capmi_s2d_stem)."""
+    return (k + 1) // 2, (4 * cin + 7) // 8 * 8
 
 
 def decoder_param_specs(C, H, E, V):
@@ -88,7 +89,8 @@ def kernel_shape(ref_shape, kind):
         return (o, kh, kw, c)
     if kind == 'stem':
         o, c, kh, kw = ref_shape
-        return (o, stem_kpad(kh, c))
+        kt, cs = stem_s2d(kh, c)
+        return (o, kt, kt, cs)
     if kind == 'dwconv':
         c, _, kh, kw = ref_shape
         return (kh, kw, c)
@@ -103,10 +105,14 @@ def to_kernel(arr, kind):
     """reference layout -> kernel layout (NumPy)."""
     if kind == 'conv':
         return np.ascontiguousarray(arr.transpose(0, 2, 3, 1))
-    if kind == 'stem':
+    if kind == 'stem':      # Ws[n][r'][q'][(ph*2+pw)*C + c] = W[n][c][2r'+ph][2q'+pw]
         o, c, kh, kw = arr.shape
-        out = np.zeros((o, stem_kpad(kh, c)), arr.dtype)
-        out[:, :kh * kw * c] = arr.transpose(0, 2, 3, 1).reshape(o, -1)
+        kt, cs = stem_s2d(kh, c)
+        out = np.zeros((o, kt, kt, cs), arr.dtype)
+        for r in range(kh):
+            for q in range(kw):
+                sub = (r % 2) * 2 + (q % 2)
+                out[:, r // 2, q // 2, sub * c:(sub + 1) * c] = arr[:, :, r, q]
         return out
     if kind == 'dwconv':
         return np.ascontiguousarray(arr[:, 0].transpose(1, 2, 0))
@@ -123,7 +129,12 @@ def to_reference(arr, kind, ref_shape):
         return np.ascontiguousarray(arr.transpose(0, 3, 1, 2))
     if kind == 'stem':
         o, c, kh, kw = ref_shape
-        return np.ascontiguousarray(arr[:, :kh * kw * c].reshape(o, kh, kw, c).transpose(0, 3, 1, 2))
+        out = np.zeros(ref_shape, arr.dtype)
+        for r in range(kh):
+            for q in range(kw):
+                sub = (r % 2) * 2 + (q % 2)
+                out[:, :, r, q] = arr[:, r // 2, q // 2, sub * c:(sub + 1) * c]
+        return out
     if kind == 'dwconv':
         return np.ascontiguousarray(arr.transpose(2, 0, 1)[:, None])
     if kind == 'fc_w':

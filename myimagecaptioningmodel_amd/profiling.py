@@ -97,6 +97,9 @@ def describe(name, args):
             return 'igemm_tn_glds_kernel', 2.0 * M * N * K, nbytes
         return 'igemm_tn_kernel<%s,64,64>' % ('bf16' if code == BF16 else 'f32'), 2.0 * M * N * K, nbytes
     es_of = lambda code: 2 if code == BF16 else 4
+    if name == 'capmi_s2d_stem':
+        B, C, H, W, Hb, Wb, Cs, code = args[2], args[3], args[4], args[5], args[7], args[8], args[9], args[10]
+        return 's2d_stem_kernel', 0.0, B * C * H * W * 4 + B * Hb * Wb * Cs * es_of(code)
     if name == 'capmi_bn_apply':
         M, C, code = args[6], args[7], args[9]
         return 'bn_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[4] else 2)

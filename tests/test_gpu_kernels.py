@@ -334,6 +334,30 @@ def test_maxpool_and_stem_im2col(dtype):
     _lib.call('capmi_igemm_nt', p(col), p(dev(wk, tdt[dtype])), p(Yc), _lib.gemm_geom(2 * Ho * Wo, Kpad), 8, Kpad, 8, None, None, 0,
               None, 0, None, 0, 0, 1, code[dtype], stream())
     check(host(Yc).reshape(2, Ho, Wo, 8), _nhwc(yc), dtype, name='stem conv')
+    # the same conv without a patch matrix: space-to-depth feed + stride-1 implicit GEMM, and its filter gradient
+    from myimagecaptioningmodel_amd.params import stem_s2d, to_kernel, to_reference
+    kt, Cs = stem_s2d(k, 3)
+    Hb, Wb = Ho + (k - 1) // 2, Wo + (k - 1) // 2
+    S2D = torch.full((2, Hb, Wb, Cs), 7.0, dtype=tdt[dtype], device=DEV)
+    _lib.call('capmi_s2d_stem', p(dev(img, torch.float32)), p(S2D), 2, 3, 20, 20, pad, Hb, Wb, Cs, code[dtype], stream())
+    g = _lib.ConvGeom(2, Hb, Wb, Cs, Ho, Wo, kt, kt, 1, 1, 0, Cs)
+    ws = to_kernel(w, 'stem')
+    assert ws.shape == (8, kt, kt, Cs) and np.array_equal(to_reference(ws, 'stem', w.shape), w)
+    Ys = torch.zeros((2 * Ho * Wo, 8), dtype=torch.float32, device=DEV)
+    _lib.call('capmi_igemm_nt', p(S2D), p(dev(ws, tdt[dtype])), p(Ys), g, 8, kt * kt * Cs, 8, None, None, 0, None, 0, None, 0, 0, 1,
+              code[dtype], stream())
+    check(host(Ys).reshape(2, Ho, Wo, 8), _nhwc(yc), dtype, name='space-to-depth stem conv')
+    dyc = rnd(rng.standard_normal(yc.shape), dtype)
+    _, dw_ref = O.conv2d_bwd(dyc, rnd(img.astype(np.float64), dtype), w, s, pad)
+    DW = torch.zeros((8, kt, kt, Cs), dtype=torch.float32, device=DEV)
+    WS = torch.zeros(_lib.WGRAD_WS_BYTES // 4, dtype=torch.float32, device=DEV)
+    _KEEP.extend([DW, WS])
+    _lib.call('capmi_igemm_tn_wgrad', p(S2D), p(dev(_nhwc(dyc), tdt[dtype])), p(DW), g, 8, 8, kt * kt * Cs, p(WS), _lib.WGRAD_WS_BYTES,
+              code[dtype], stream())
+    _lib.call('capmi_s2d_stem_mask_grad', p(DW), 8, 3, k, Cs, stream())
+    got = host(DW)
+    check(to_reference(got, 'stem', w.shape), dw_ref, dtype, scale=np.abs(dw_ref).max(), name='stem filter gradient')
+    assert np.count_nonzero(got) <= 8 * k * k * 3            # every structural-zero slot is zero
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])

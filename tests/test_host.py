@@ -118,9 +118,14 @@ def test_param_store_names_layouts_and_round_trip():
     np.testing.assert_array_equal(st.view('conv2_1_dwise_weights').numpy(), ref['conv2_1_dwise_weights'][:, 0].transpose(1, 2, 0))
     np.testing.assert_array_equal(st.view('fc_5.w_0').numpy(), ref['fc_5.w_0'].T)
     np.testing.assert_array_equal(st.view('lstm_w').numpy(), ref['lstm_w'].T)
-    stem = st.view('conv1_1_weights').numpy()
-    assert stem.shape == (32, 32) and np.all(stem[:, 27:] == 0)
-    np.testing.assert_array_equal(stem[:, :27], ref['conv1_1_weights'].transpose(0, 2, 3, 1).reshape(32, 27))
+    stem = st.view('conv1_1_weights').numpy()                   # space-to-depth form [Cout][kt][kt][Cs] (capmi_s2d_stem)
+    wref = ref['conv1_1_weights']
+    assert stem.shape == (32, 2, 2, 16) and np.count_nonzero(stem) <= wref.size
+    for r in range(3):
+        for q in range(3):
+            sub = (r % 2) * 2 + (q % 2)
+            np.testing.assert_array_equal(stem[:, r // 2, q // 2, sub * 3:sub * 3 + 3], wref[:, :, r, q])
+    assert np.all(stem[:, :, :, 12:] == 0) and np.all(stem[:, 1, :, 6:12] == 0) and np.all(stem[:, :, 1, 3:6] == 0)
 
 
 def test_frozen_encoder_is_excluded_from_the_optimizer_range():
