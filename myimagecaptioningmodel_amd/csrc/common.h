@@ -89,6 +89,12 @@ template <> __device__ __forceinline__ bf16 from_f32<bf16>(float x) { return (bf
 // ------------------------------------------------------------------ activations
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }   // ocml: ~1 ulp, keeps f32 parity
+// tanh for kernels whose result is rounded to bf16 anyway: 1 - 2/(1 + e^{2x}) on the hardware exp / rcp
+// (absolute error ~1e-7; exact limits +-1).  The f32 instantiations keep the ocml function.
+template <typename T> __device__ __forceinline__ float tanh_for(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ float tanh_for<bf16>(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
+}
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
         case CAPMI_ACT_RELU: return fmaxf(x, 0.f);

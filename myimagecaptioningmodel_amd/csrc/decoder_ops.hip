@@ -274,32 +274,43 @@ __global__ __launch_bounds__(256) void attn_singleton_bwd_kernel(const T* __rest
     for (int k = 0; k < K; ++k) vstore<T>(dVt + (((int64_t)b * K + k) * cpr + cc) * VEC, ov);
 }
 
-// slots mode forward: one workgroup per row m = (t, b).
+// slots mode forward: one workgroup per row m = (t, b).  Phase 1: one wave per slot, e_k by a wave
+// reduction; softmax over the K+1 slots; phase 3: thread (chunk, slot group) accumulates its slots'
+// alpha_k * ctx_k in registers, the four slot groups meet in LDS (no atomics).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_slots_fwd_kernel(const T* __restrict__ Ve, const T* __restrict__ Vt, const T* __restrict__ q,
                                                              const T* __restrict__ se, const T* __restrict__ s, const T* __restrict__ p,
                                                              const T* __restrict__ w10, const float* __restrict__ b10, T* out, float* alpha,
                                                              int B, int K, int H) {
     constexpr int VEC = Vec<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [H] ctx  | [K+1] e | [16] scratch
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [4][H] ctx partials | [K+1] e | [16] scratch
     float* ctx = smem;
-    float* ev = smem + H;
+    float* ev = smem + 4 * H;
     float* scratch = ev + (K + 1);
     const int m = blockIdx.x, b = m % B;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cpr = H / VEC;
-    for (int i = tid; i < H; i += 256) ctx[i] = 0.f;
-    // e_k = sum_h tanh(feat_emb[k,h] + q[h]) * w10[h] + b10  -- one wave per slot
-    for (int k = wave; k <= K; k += 4) {
-        const T* row = k < K ? Ve + ((int64_t)b * K + k) * H : se + (int64_t)m * H;
-        float part = 0.f;
+    // e_k = sum_h tanh(feat_emb[k,h] + q[h]) * w10[h] + b10  -- one wave per slot, two slots in flight
+    for (int k0 = wave; k0 <= K; k0 += 8) {
+        const int k1 = k0 + 4;
+        const T* row0 = k0 < K ? Ve + ((int64_t)b * K + k0) * H : se + (int64_t)m * H;
+        const T* row1 = k1 < K ? Ve + ((int64_t)b * K + k1) * H : se + (int64_t)m * H;
+        float part0 = 0.f, part1 = 0.f;
         for (int cc = lane; cc < cpr; cc += 64) {
-            Vec<T> a = vload<T>(row + cc * VEC), qq = vload<T>(q + (int64_t)m * H + cc * VEC), ww = vload<T>(w10 + cc * VEC);
+            Vec<T> qq = vload<T>(q + (int64_t)m * H + cc * VEC), ww = vload<T>(w10 + cc * VEC);
+            Vec<T> a0 = vload<T>(row0 + cc * VEC), a1 = k1 <= K ? vload<T>(row1 + cc * VEC) : vzero<T>();
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) part += tanhf_(a.get(v) + qq.get(v)) * ww.get(v);
+            for (int v = 0; v < VEC; ++v) {
+                part0 += tanh_for<T>(a0.get(v) + qq.get(v)) * ww.get(v);
+                part1 += tanh_for<T>(a1.get(v) + qq.get(v)) * ww.get(v);
+            }
         }
-        part = wave_sum(part);
-        if (lane == 0) ev[k] = part + b10[0];
+        part0 = wave_sum(part0);
+        part1 = wave_sum(part1);
+        if (lane == 0) {
+            ev[k0] = part0 + b10[0];
+            if (k1 <= K) ev[k1] = part1 + b10[0];
+        }
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -315,21 +326,31 @@ __global__ __launch_bounds__(256) void attn_slots_fwd_kernel(const T* __restrict
         alpha[(int64_t)m * (K + 1) + k] = a;
     }
     __syncthreads();
-    // ctx[h] = sum_k alpha_k * ctx_all[k,h]
-    for (int idx = tid; idx < (K + 1) * cpr; idx += 256) {
-        int k = idx / cpr, cc = idx % cpr;
-        const T* row = k < K ? Vt + ((int64_t)b * K + k) * H : s + (int64_t)m * H;
-        Vec<T> x = vload<T>(row + cc * VEC);
-        float a = ev[k];
+    // ctx[h] = sum_k alpha_k * ctx_all[k,h]: slot group `wave` takes k = wave, wave+4, ...
+    for (int cc = lane; cc < cpr; cc += 64) {
+        float acc[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) atomicAdd(&ctx[cc * VEC + v], a * x.get(v));
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+#pragma unroll 4
+        for (int k = wave; k <= K; k += 4) {
+            const T* row = k < K ? Vt + ((int64_t)b * K + k) * H : s + (int64_t)m * H;
+            Vec<T> x = vload<T>(row + cc * VEC);
+            const float a = ev[k];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] += a * x.get(v);
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ctx[wave * H + cc * VEC + v] = acc[v];
     }
     __syncthreads();
     const float inv = 1.f / (float)(K + 1);
     for (int cc = tid; cc < cpr; cc += 256) {
         Vec<T> pv = vload<T>(p + (int64_t)m * H + cc * VEC), ov;
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) ov.set(v, ctx[cc * VEC + v] * inv + pv.get(v));
+        for (int v = 0; v < VEC; ++v) {
+            const int h = cc * VEC + v;
+            ov.set(v, (ctx[h] + ctx[H + h] + ctx[2 * H + h] + ctx[3 * H + h]) * inv + pv.get(v));
+        }
         vstore<T>(out + (int64_t)m * H + cc * VEC, ov);
     }
 }
@@ -345,7 +366,7 @@ extern "C" int capmi_ada_attention_fwd(const void* Ve, const void* Vt, const voi
         if (!slots) {
             hipLaunchKernelGGL(attn_singleton_fwd_kernel<T>, dim3(cdiv((int64_t)B * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)Vt, (const T*)s, (const T*)p, (T*)out, T_, B, K, cpr);
         } else {
-            size_t sh = (size_t)(H + K + 1 + 16) * sizeof(float);
+            size_t sh = (size_t)(4 * H + K + 1 + 16) * sizeof(float);
             hipLaunchKernelGGL(attn_slots_fwd_kernel<T>, dim3(T_ * B), dim3(256), sh, (hipStream_t)stream, (const T*)Ve, (const T*)Vt, (const T*)q, (const T*)se,
                                (const T*)s, (const T*)p, (const T*)w10, b10, (T*)out, alpha, B, K, H);
         }
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(256) void attn_slots_bwd2_kernel(const T* __restric
                 float a = alpha[m * (K + 1) + k] * inv, d = de[m * (K + 1) + k];
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    float z = tanhf_(ve[j][v] + qv.get(v));
+                    float z = tanh_for<T>(ve[j][v] + qv.get(v));
                     float dz = d * ww[v] * (1.f - z * z);
                     aVe[j][v] += dz;
                     dql[v] += dz;
@@ -462,7 +483,7 @@ __global__ __launch_bounds__(256) void attn_slots_bwd2_kernel(const T* __restric
             Vec<T> sv = vload<T>(se + m * H + chunk * VEC), o;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                float z = tanhf_(sv.get(v) + qv.get(v));
+                float z = tanh_for<T>(sv.get(v) + qv.get(v));
                 float dz = d * ww[v] * (1.f - z * z);
                 o.set(v, dz);
                 dql[v] += dz;
