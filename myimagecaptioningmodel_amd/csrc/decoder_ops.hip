@@ -420,24 +420,25 @@ __global__ __launch_bounds__(256) void attn_slots_bwd1_kernel(const T* __restric
     }
 }
 
-// slots backward, phase 2: workgroup per (b, tile of TH 16-byte chunks of h).  Threads = TH chunk
-// columns x (256/TH) slot groups; dVt/dVe accumulate over t in registers, dq/dw10 meet in LDS.
-template <typename T, int TH, int MAXK>
+// slots backward, phase 2: workgroup per (b, tile of TH = 8 16-byte chunks of h).  Threads = 8 chunk columns x
+// 32 slot groups; dVt/dVe accumulate over t in registers; dq (a sum over the slots) meets by wave shuffles
+// + one LDS hand-off per step (double-buffered: one barrier per step); the next step's operands are
+// loaded before the current step is computed.
+template <typename T, int MAXK>
 __global__ __launch_bounds__(256) void attn_slots_bwd2_kernel(const T* __restrict__ Ve, const T* __restrict__ q, const T* __restrict__ se,
                                                               const T* __restrict__ w10, const float* __restrict__ alpha, const float* __restrict__ de,
                                                               const T* __restrict__ dout, T* dVt, T* dVe, T* dq, T* dse, float* dw10,
                                                               int T_, int B, int K, int H) {
     constexpr int VEC = Vec<T>::N;
-    constexpr int KG = 256 / TH;
-    __shared__ float sdq[TH * VEC], sdw[TH * VEC];
-    const int tid = threadIdx.x;
+    constexpr int TH = 8, KG = 256 / TH;
+    __shared__ float sdq[2][4][TH * VEC], sdw[4][TH * VEC];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cc = tid % TH, kg = tid / TH;
     const int tiles = (H / VEC + TH - 1) / TH;
     const int b = blockIdx.x / tiles, chunk = (blockIdx.x % tiles) * TH + cc;
     const bool cok = chunk * VEC < H;
     const float inv = 1.f / (float)(K + 1);
     float aVt[MAXK][VEC], aVe[MAXK][VEC], ve[MAXK][VEC], ww[VEC], dwl[VEC];
-    if (tid < TH * VEC) sdw[tid] = 0.f;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { ww[v] = 0.f; dwl[v] = 0.f; }
     if (cok) {
@@ -452,54 +453,78 @@ __global__ __launch_bounds__(256) void attn_slots_bwd2_kernel(const T* __restric
 #pragma unroll
         for (int v = 0; v < VEC; ++v) { ve[j][v] = x.get(v); aVt[j][v] = 0.f; aVe[j][v] = 0.f; }
     }
+    // operands of one step: this thread's slots' alpha / de, the row's dout / q chunk, the sentinel's de and se chunk
+    struct Step { float a[MAXK], d[MAXK], dK; Vec<T> dv, qv, sv; };
+    auto load_step = [&](int t) {
+        Step s;
+        const int64_t m = (int64_t)t * B + b;
+#pragma unroll
+        for (int j = 0; j < MAXK; ++j) {
+            const int k = kg + j * KG;
+            s.a[j] = k < K ? alpha[m * (K + 1) + k] * inv : 0.f;
+            s.d[j] = k < K ? de[m * (K + 1) + k] : 0.f;
+        }
+        s.dK = de[m * (K + 1) + K];
+        s.dv = cok ? vload<T>(dout + m * H + chunk * VEC) : vzero<T>();
+        s.qv = cok ? vload<T>(q + m * H + chunk * VEC) : vzero<T>();
+        s.sv = (cok && kg == 0) ? vload<T>(se + m * H + chunk * VEC) : vzero<T>();
+        return s;
+    };
+    Step cur = load_step(0);
     for (int t = 0; t < T_; ++t) {
         const int64_t m = (int64_t)t * B + b;
-        __syncthreads();
-        if (tid < TH * VEC) sdq[tid] = 0.f;
-        __syncthreads();
+        Step nxt = cur;
+        if (t + 1 < T_) nxt = load_step(t + 1);
         float dql[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) dql[v] = 0.f;
-        Vec<T> dv = cok ? vload<T>(dout + m * H + chunk * VEC) : vzero<T>();
-        Vec<T> qv = cok ? vload<T>(q + m * H + chunk * VEC) : vzero<T>();
 #pragma unroll
         for (int j = 0; j < MAXK; ++j) {
-            int k = kg + j * KG;
-            if (k < K) {
-                float a = alpha[m * (K + 1) + k] * inv, d = de[m * (K + 1) + k];
+            const float a = cur.a[j], dd = cur.d[j];       // zero beyond K: contributes nothing
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) {
-                    float z = tanh_for<T>(ve[j][v] + qv.get(v));
-                    float dz = d * ww[v] * (1.f - z * z);
-                    aVe[j][v] += dz;
-                    dql[v] += dz;
-                    dwl[v] += d * z;
-                    aVt[j][v] += dv.get(v) * a;
-                }
+            for (int v = 0; v < VEC; ++v) {
+                float z = tanh_for<T>(ve[j][v] + cur.qv.get(v));
+                float dz = dd * ww[v] * (1.f - z * z);
+                aVe[j][v] += dz;
+                dql[v] += dz;
+                dwl[v] += dd * z;
+                aVt[j][v] += cur.dv.get(v) * a;
             }
         }
         if (kg == 0 && cok) {      // sentinel slot K
-            float d = de[m * (K + 1) + K];
-            Vec<T> sv = vload<T>(se + m * H + chunk * VEC), o;
+            Vec<T> o;
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                float z = tanh_for<T>(sv.get(v) + qv.get(v));
-                float dz = d * ww[v] * (1.f - z * z);
+                float z = tanh_for<T>(cur.sv.get(v) + cur.qv.get(v));
+                float dz = cur.dK * ww[v] * (1.f - z * z);
                 o.set(v, dz);
                 dql[v] += dz;
-                dwl[v] += d * z;
+                dwl[v] += cur.dK * z;
             }
             vstore<T>(dse + m * H + chunk * VEC, o);
         }
+        // dq: sum over the 32 slot groups = lanes with equal (lane & 7), then over the 4 waves
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) atomicAdd(&sdq[cc * VEC + v], dql[v]);
+        for (int v = 0; v < VEC; ++v) {
+            float x = dql[v];
+            x += __shfl_xor(x, 8);
+            x += __shfl_xor(x, 16);
+            x += __shfl_xor(x, 32);
+            dql[v] = x;
+        }
+        if (lane < TH) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) sdq[t & 1][wave][lane * VEC + v] = dql[v];
+        }
         __syncthreads();
         if (kg == 0 && cok) {
             Vec<T> o;
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) o.set(v, sdq[cc * VEC + v]);
+            for (int v = 0; v < VEC; ++v)
+                o.set(v, sdq[t & 1][0][cc * VEC + v] + sdq[t & 1][1][cc * VEC + v] + sdq[t & 1][2][cc * VEC + v] + sdq[t & 1][3][cc * VEC + v]);
             vstore<T>(dq + m * H + chunk * VEC, o);
         }
+        cur = nxt;
     }
 #pragma unroll
     for (int j = 0; j < MAXK; ++j) {
@@ -513,11 +538,22 @@ __global__ __launch_bounds__(256) void attn_slots_bwd2_kernel(const T* __restric
         }
     }
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) atomicAdd(&sdw[cc * VEC + v], dwl[v]);
+    for (int v = 0; v < VEC; ++v) {
+        float x = dwl[v];
+        x += __shfl_xor(x, 8);
+        x += __shfl_xor(x, 16);
+        x += __shfl_xor(x, 32);
+        dwl[v] = x;
+    }
+    if (lane < TH) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) sdw[wave][lane * VEC + v] = dwl[v];
+    }
     __syncthreads();
     if (kg == 0 && cok) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) atomicAdd(&dw10[chunk * VEC + v], sdw[cc * VEC + v]);
+        for (int v = 0; v < VEC; ++v)
+            atomicAdd(&dw10[chunk * VEC + v], sdw[0][cc * VEC + v] + sdw[1][cc * VEC + v] + sdw[2][cc * VEC + v] + sdw[3][cc * VEC + v]);
     }
 }
 
@@ -534,13 +570,17 @@ extern "C" int capmi_ada_attention_bwd(const void* Ve, const void* Vt, const voi
         if (!slots) {
             hipLaunchKernelGGL(attn_singleton_bwd_kernel<T>, dim3(cdiv((int64_t)B * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)dout, (T*)ds, (T*)dVt, T_, B, K, cpr);
         } else {
-            constexpr int TH = 8, MAXK = 8;
-            CAPMI_CHECK(K <= MAXK * (256 / TH), "capmi_ada_attention_bwd: K=%d above the supported %d", K, MAXK * (256 / TH));
+            constexpr int TH = 8;
+            CAPMI_CHECK(K <= 8 * (256 / TH), "capmi_ada_attention_bwd: K=%d above the supported %d", K, 8 * (256 / TH));
             size_t sh = (size_t)(K + 1 + 16) * sizeof(float);
             hipLaunchKernelGGL(attn_slots_bwd1_kernel<T>, dim3(T_ * B), dim3(256), sh, (hipStream_t)stream, (const T*)Vt, (const T*)s, alpha, (const T*)dout, (T*)ds, de, db10, B, K, H);
             int tiles = cdiv(cpr, TH);
-            hipLaunchKernelGGL((attn_slots_bwd2_kernel<T, TH, MAXK>), dim3(B * tiles), dim3(256), 0, (hipStream_t)stream, (const T*)Ve, (const T*)q, (const T*)se,
-                               (const T*)w10, alpha, de, (const T*)dout, (T*)dVt, (T*)dVe, (T*)dq, (T*)dse, dw10, T_, B, K, H);
+            if (K <= 2 * (256 / TH))
+                hipLaunchKernelGGL((attn_slots_bwd2_kernel<T, 2>), dim3(B * tiles), dim3(256), 0, (hipStream_t)stream, (const T*)Ve, (const T*)q, (const T*)se,
+                                   (const T*)w10, alpha, de, (const T*)dout, (T*)dVt, (T*)dVe, (T*)dq, (T*)dse, dw10, T_, B, K, H);
+            else
+                hipLaunchKernelGGL((attn_slots_bwd2_kernel<T, 8>), dim3(B * tiles), dim3(256), 0, (hipStream_t)stream, (const T*)Ve, (const T*)q, (const T*)se,
+                                   (const T*)w10, alpha, de, (const T*)dout, (T*)dVt, (T*)dVe, (T*)dq, (T*)dse, dw10, T_, B, K, H);
         }
     });
     CAPMI_LAUNCH_CHECK("capmi_ada_attention_bwd");
