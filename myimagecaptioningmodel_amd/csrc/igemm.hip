@@ -653,7 +653,7 @@ __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NST, bool RED>
+template <int BM, int BN, int NST, bool RED, bool LIN>
 __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int nblocks) {
     typedef bf16 T;
     constexpr int BK = 32, WMW = 4;
@@ -690,12 +690,24 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     }
     KPos kp = k_pos(chunk * 8, a.g);
     const T* zero = reinterpret_cast<const T*>(capmi_zero_page);
+    // LIN: 1x1 / stride 1 / no padding -- A(m, k) = x[m*ldx + k], no tap arithmetic in the loop
+    const T* arow[ACNT];
+#pragma unroll
+    for (int i = 0; i < ACNT; ++i) {
+        const int m = m0 + i * 64 + (tid >> 2);
+        arow[i] = m < a.M ? X + (int64_t)m * a.g.ldx : nullptr;
+    }
     auto issue_stage = [&](int st) {    // DMA of the tile at the current kp into ring slot st; advances kp
         char* base = smem + st * STB + wave * 1024;
 #pragma unroll
         for (int i = 0; i < ACNT; ++i) {
-            const int64_t off = a_offset(rp[i], kp, a.K, a.g);
-            const T* src = off >= 0 ? X + off : zero;
+            const T* src;
+            if constexpr (LIN) {
+                src = (arow[i] && kp.k < a.K) ? arow[i] + kp.k : zero;
+            } else {
+                const int64_t off = a_offset(rp[i], kp, a.K, a.g);
+                src = off >= 0 ? X + off : zero;
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
         }
@@ -705,7 +717,8 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + AOPB + i * 4096), 16, 0, 0);
         }
-        k_advance(kp, BK, a.g);
+        if constexpr (LIN) kp.k += BK;
+        else k_advance(kp, BK, a.g);
     };
 
     f32x4 acc[TM][TN];
@@ -755,9 +768,9 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
 }
 
-template <int BM, int BN, int NST, bool RED = false>
+template <int BM, int BN, int NST, bool RED = false, bool LIN = false>
 __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_kernel(IGemmArgs a) {
-    nt_glds_body<BM, BN, NST, RED>(a, blockIdx.x, gridDim.x);
+    nt_glds_body<BM, BN, NST, RED, LIN>(a, blockIdx.x, gridDim.x);
 }
 
 // Several independent problems (the parity classes of a strided data gradient) in ONE launch: the
@@ -774,7 +787,7 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
     const int b = blockIdx.x;
     int p = 0;
     while (p + 1 < g.count && b >= g.first[p + 1]) ++p;
-    nt_glds_body<BM, BN, NST, false>(g.a[p], b - g.first[p], g.first[p + 1] - g.first[p]);
+    nt_glds_body<BM, BN, NST, false, false>(g.a[p], b - g.first[p], g.first[p + 1] - g.first[p]);
 }
 
 // ------------------------------------------------------------------ skinny NT kernel (M <= 64)
@@ -987,23 +1000,21 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
     }
     const NtCfg c = nt_cfg(a.M, N, a.K, dtype);
     if (dtype == CAPMI_BF16) {
-        if (c.wmw == 5) {       // 64x64 LDS-DMA tiles
-            const int64_t tiles = (int64_t)cdiv(a.M, 64) * cdiv(a.N, 64);
-            if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 64, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 64, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds64x64)");
-            return 0;
-        }
-        if (c.bn == 128) {      // LDS-DMA pipeline kernels
-            const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(a.N, 128);
-            CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
-            if (c.bm == 128 && a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 128, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 128, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 128, 3, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_glds_kernel<64, 128, 3>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-            CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
-            return 0;
-        }
+        const bool lin = g->kh == 1 && g->kw == 1 && g->sd == 1 && g->up == 1 && g->pad == 0 && g->Hi == g->Ho && g->Wi == g->Wo;
+#define CAPMI_GLDS(BM_, BN_)                                                                                                  \
+    do {                                                                                                                      \
+        const int64_t tiles = (int64_t)cdiv(a.M, BM_) * cdiv(a.N, BN_);                                                       \
+        CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");                                                   \
+        if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, true, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);   \
+        else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);         \
+        CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");                                                                           \
+        return 0;                                                                                                             \
+    } while (0)
+        if (c.wmw == 5) CAPMI_GLDS(64, 64);         // 64x64 LDS-DMA tiles
+        if (c.bn == 128 && c.bm == 128) CAPMI_GLDS(128, 128);
+        if (c.bn == 128) CAPMI_GLDS(64, 128);
+#undef CAPMI_GLDS
         if (c.bm == 128 && c.bn == 64) return launch_nt<bf16, 128, 64, 4>(a, st);
         return launch_nt<bf16, 64, 64, 4>(a, st);
     } else if (dtype == CAPMI_F32) {
