@@ -653,7 +653,7 @@ __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NST, bool RED, bool LIN>
+template <int BM, int BN, int NST, bool RED, int LIN>
 __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int nblocks) {
     typedef bf16 T;
     constexpr int BK = 32, WMW = 4;
@@ -690,20 +690,24 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     }
     KPos kp = k_pos(chunk * 8, a.g);
     const T* zero = reinterpret_cast<const T*>(capmi_zero_page);
-    // LIN: 1x1 / stride 1 / no padding -- A(m, k) = x[m*ldx + k], no tap arithmetic in the loop
+    // addressing mode LIN: 1 = 1x1 / no padding (any stride): A(m, k) = x[base(m) + k], no tap arithmetic in the
+    // loop; 2 = up == 1 and Cin >= BK: taps tracked with selects, no branches; 0 = general (a_offset)
     const T* arow[ACNT];
 #pragma unroll
-    for (int i = 0; i < ACNT; ++i) {
-        const int m = m0 + i * 64 + (tid >> 2);
-        arow[i] = m < a.M ? X + (int64_t)m * a.g.ldx : nullptr;
-    }
+    for (int i = 0; i < ACNT; ++i) arow[i] = rp[i].ok ? X + rp[i].base : nullptr;
+    const int Hi = a.g.Hi, Wi = a.g.Wi, ldx = a.g.ldx, Cin = a.g.Cin, kw = a.g.kw;
     auto issue_stage = [&](int st) {    // DMA of the tile at the current kp into ring slot st; advances kp
         char* base = smem + st * STB + wave * 1024;
 #pragma unroll
         for (int i = 0; i < ACNT; ++i) {
             const T* src;
-            if constexpr (LIN) {
+            if constexpr (LIN == 1) {
                 src = (arow[i] && kp.k < a.K) ? arow[i] + kp.k : zero;
+            } else if constexpr (LIN == 2) {
+                const int hn = rp[i].hb + kp.r, wn = rp[i].wb + kp.q;
+                const bool ok = arow[i] && kp.k < a.K && (unsigned)hn < (unsigned)Hi && (unsigned)wn < (unsigned)Wi;
+                src = arow[i] + ((kp.r * Wi + kp.q) * ldx + kp.c);
+                src = ok ? src : zero;
             } else {
                 const int64_t off = a_offset(rp[i], kp, a.K, a.g);
                 src = off >= 0 ? X + off : zero;
@@ -717,8 +721,17 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + AOPB + i * 4096), 16, 0, 0);
         }
-        if constexpr (LIN) kp.k += BK;
-        else k_advance(kp, BK, a.g);
+        if constexpr (LIN == 1) kp.k += BK;
+        else if constexpr (LIN == 2) {       // Cin >= BK: one channel wrap at most per step
+            kp.k += BK;
+            kp.c += BK;
+            const bool wc = kp.c >= Cin;
+            kp.c -= wc ? Cin : 0;
+            kp.q += wc ? 1 : 0;
+            const bool wq = kp.q == kw;
+            kp.q = wq ? 0 : kp.q;
+            kp.r += wq ? 1 : 0;
+        } else k_advance(kp, BK, a.g);
     };
 
     f32x4 acc[TM][TN];
@@ -768,7 +781,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
 }
 
-template <int BM, int BN, int NST, bool RED = false, bool LIN = false>
+template <int BM, int BN, int NST, bool RED = false, int LIN = 0>
 __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_kernel(IGemmArgs a) {
     nt_glds_body<BM, BN, NST, RED, LIN>(a, blockIdx.x, gridDim.x);
 }
@@ -787,7 +800,7 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
     const int b = blockIdx.x;
     int p = 0;
     while (p + 1 < g.count && b >= g.first[p + 1]) ++p;
-    nt_glds_body<BM, BN, NST, false, false>(g.a[p], b - g.first[p], g.first[p + 1] - g.first[p]);
+    nt_glds_body<BM, BN, NST, false, 0>(g.a[p], b - g.first[p], g.first[p + 1] - g.first[p]);
 }
 
 // ------------------------------------------------------------------ skinny NT kernel (M <= 64)
@@ -1000,14 +1013,16 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
     }
     const NtCfg c = nt_cfg(a.M, N, a.K, dtype);
     if (dtype == CAPMI_BF16) {
-        const bool lin = g->kh == 1 && g->kw == 1 && g->sd == 1 && g->up == 1 && g->pad == 0 && g->Hi == g->Ho && g->Wi == g->Wo;
+        const bool lin = g->kh == 1 && g->kw == 1 && g->up == 1 && g->pad == 0 && (g->Ho - 1) * g->sd < g->Hi && (g->Wo - 1) * g->sd < g->Wi;
+        const bool conv1 = !lin && g->up == 1 && g->Cin >= 32;
 #define CAPMI_GLDS(BM_, BN_)                                                                                                  \
     do {                                                                                                                      \
         const int64_t tiles = (int64_t)cdiv(a.M, BM_) * cdiv(a.N, BN_);                                                       \
         CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");                                                   \
-        if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, true, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);   \
-        else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, true>), dim3((unsigned)tiles), dim3(256), 0, st, a); \
-        else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, false>), dim3((unsigned)tiles), dim3(256), 0, st, a);         \
+        if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, true, 0>), dim3((unsigned)tiles), dim3(256), 0, st, a);       \
+        else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, 1>), dim3((unsigned)tiles), dim3(256), 0, st, a);    \
+        else if (conv1) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, 2>), dim3((unsigned)tiles), dim3(256), 0, st, a);  \
+        else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, 0>), dim3((unsigned)tiles), dim3(256), 0, st, a);             \
         CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");                                                                           \
         return 0;                                                                                                             \
     } while (0)
