@@ -795,12 +795,12 @@ struct NtGroup {
     int first[NT_GROUP_MAX + 1];
     int count;
 };
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int LIN>
 __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_group_kernel(NtGroup g) {
     const int b = blockIdx.x;
     int p = 0;
     while (p + 1 < g.count && b >= g.first[p + 1]) ++p;
-    nt_glds_body<BM, BN, NST, false, 0>(g.a[p], b - g.first[p], g.first[p + 1] - g.first[p]);
+    nt_glds_body<BM, BN, NST, false, LIN>(g.a[p], b - g.first[p], g.first[p + 1] - g.first[p]);
 }
 
 // ------------------------------------------------------------------ skinny NT kernel (M <= 64)
@@ -1083,7 +1083,7 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
     for (int first = 0; first < count; first += NT_GROUP_MAX) {
         const int n = count - first < NT_GROUP_MAX ? count - first : NT_GROUP_MAX;
         NtGroup grp;
-        bool fuse = dtype == CAPMI_BF16 && n > 1;
+        bool fuse = dtype == CAPMI_BF16 && n > 1, conv1 = true;
         long long blocks = 0;
         for (int i = 0; i < n; ++i) {
             const capmi_igemm_nt_call& c = calls[first + i];
@@ -1091,13 +1091,15 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
                            0, c.dact, 0, 0, nullptr, dtype)) return 1;
             const IGemmArgs& a = grp.a[i];
             fuse = fuse && !nt_uses_skinny(&c.g, a.M, a.K, false, dtype) && nt_cfg(a.M, a.N, a.K, dtype).bn == 128 && nt_cfg(a.M, a.N, a.K, dtype).wmw == 4;
+            conv1 = conv1 && c.g.up == 1 && c.g.Cin >= 32;
             grp.first[i] = (int)blocks;
             blocks += ((long long)cdiv(a.M, 64) * cdiv(a.N, 128) + 7) / 8 * 8;      // ranges start at multiples of 8 (XCD order)
         }
         grp.first[n] = (int)blocks;
         grp.count = n;
         if (fuse && blocks < (1ll << 31)) {
-            hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt_group");
         } else {
             for (int i = 0; i < n; ++i) {
