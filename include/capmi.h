@@ -215,6 +215,20 @@ int capmi_lstm_cell_fwd(const void* gates, const void* c_prev, void* h, void* c,
 int capmi_lstm_cell_bwd(const void* gates, const void* c_prev, const void* c, const void* dh,
                         const void* dc_in, void* dgates, void* dc_prev, int dc_prev_accumulate,
                         int B, int H, int dtype, void* stream);
+/* One time step of the recurrence in ONE launch (B <= 64, H % 128 == 0, H >= 256: capmi_lstm_step_supported):
+ *   fwd: gates[b][g*H+u] (in: the input part x_t.Wx^T + b, out: the full pre-activations, same precision as
+ *        capmi_igemm_nt would store) += h_prev[b][:] . wh[g*H+u][:]   (wh: [4H] rows of stride ldw, the recurrent
+ *        columns of lstm_w), then the lstm_unit cell (gate order i,f,o,g) -> c, h.   c_prev NULL = zeros.
+ *   bwd: dh = dh_in + dgates_t . whT^T (whT: [H] rows of stride ldwT, reduction over the 4H gates), then the cell
+ *        backward of the PREVIOUS step: gates_prev, c_prev (its incoming cell state, NULL = zeros), c (its outgoing
+ *        one), dc_in -> dgates_prev, dc_prev (+= when dc_prev_accumulate; NULL = not needed).
+ * Same arithmetic and rounding points as capmi_igemm_nt + capmi_lstm_cell_{fwd,bwd} (model_adaAttention_aic.py:87-88). */
+int capmi_lstm_step_supported(int B, int H, int dtype);
+int capmi_lstm_step_fwd(const void* h_prev, const void* wh, int ldw, void* gates, const void* c_prev, void* h, void* c,
+                        int B, int H, int dtype, void* stream);
+int capmi_lstm_step_bwd(const void* dgates_t, const void* whT, int ldwT, const void* dh_in, const void* gates_prev,
+                        const void* c_prev, const void* c, const void* dc_in, void* dgates_prev, void* dc_prev,
+                        int dc_prev_accumulate, int B, int H, int dtype, void* stream);
 /* visual sentinel (:91-92): s = sigmoid(sgpre) * tanh(c); bwd -> dsgpre, dc. */
 int capmi_sentinel_fwd(const void* sgpre, const void* c, void* s, int64_t n, int dtype, void* stream);
 int capmi_sentinel_bwd(const void* ds, const void* sgpre, const void* c, void* dsgpre, void* dc,

@@ -67,6 +67,8 @@ SIGNATURES = {
     'capmi_bcast_rows_bwd': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'capmi_lstm_cell_fwd': [_p, _p, _p, _p, _i, _i, _i, _p],
     'capmi_lstm_cell_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_lstm_step_fwd': [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    'capmi_lstm_step_bwd': [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_sentinel_fwd': [_p, _p, _p, _l, _i, _p],
     'capmi_sentinel_bwd': [_p, _p, _p, _p, _p, _l, _i, _p],
     'capmi_ada_attention_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -93,6 +95,7 @@ QUERIES = {
     'capmi_igemm_nt_stats_part_rows': [_i, _i, _i, _i],
     'capmi_igemm_nt_bnred_part_rows': [_g, _i, _i],
     'capmi_bn_stats_part_rows': [_i, _i, _i],
+    'capmi_lstm_step_supported': [_i, _i, _i],
     'capmi_bn_bwd_ws_floats': [_i, _i, _i],
 }
 

@@ -92,6 +92,10 @@ __device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }   // ocml:
 // tanh for kernels whose result is rounded to bf16 anyway: 1 - 2/(1 + e^{2x}) on the hardware exp / rcp
 // (absolute error ~1e-7; exact limits +-1).  The f32 instantiations keep the ocml function.
 template <typename T> __device__ __forceinline__ float tanh_for(float x) { return tanhf(x); }
+template <typename T> __device__ __forceinline__ float sigmoid_for(float x) { return 1.f / (1.f + expf(-x)); }
+template <> __device__ __forceinline__ float sigmoid_for<bf16>(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 template <> __device__ __forceinline__ float tanh_for<bf16>(float x) {
     return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.8853900817779268f));
 }

@@ -931,6 +931,208 @@ __global__ __launch_bounds__(256) void igemm_nt_skinny_kernel(IGemmArgs a) {
 //                  convs are bound by memory concurrency, not by MFMA
 //   bf16, N <= 64: 128x64 / 64x64, 4x1 waves (8-byte stores)
 //   f32          : 2x2 waves, tiles sized for 64 KiB of static LDS
+// ------------------------------------------------------------------ fused LSTM steps (skinny GEMM + pointwise cell)
+// The recurrence is 2T dependent launches on a nearly idle chip; each fused kernel is one skinny product (64 x 32
+// tile per workgroup, K split over the four waves, fragments straight from L2) with the lstm_unit cell as its
+// epilogue, so a time step is ONE launch in each direction.
+template <typename T>
+__device__ __forceinline__ void skinny_product(const T* const (&arow)[4], const bool (&aok)[4], const T* const (&brow)[2], int kper,
+                                               float (*red)[8][64][4], float (&v)[4][2]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < kper; k += 32) {
+        Frag<T> af[4], bf[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i].load(arow[i] + k);
+            if (!aok[i]) af[i] = Frag<T>{};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j].load(brow[j] + k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma16(acc[i][j], af[i], bf[j]);
+    }
+    // cross-wave reduction: wave w finishes rows 16w..16w+15
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&red[wave][i * 2 + j][lane][0]) = acc[i][j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        f32x4 sm = *reinterpret_cast<const f32x4*>(&red[0][wave * 2 + j][lane][0]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) sm += *reinterpret_cast<const f32x4*>(&red[w][wave * 2 + j][lane][0]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r][j] = sm[r];
+    }
+}
+
+// forward step: gates[b][g*H+u] (in: input part x_t.Wx + bias) += h_prev . Wh^T, then i,f,o,g -> c, h.
+// Workgroup = 8 hidden units x 4 gates (tile column 8g + u).
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(const T* __restrict__ h_prev, const T* __restrict__ wh, int ldw, T* gates,
+                                                            const T* __restrict__ c_prev, T* h, T* c, int B, int H) {
+    __shared__ __attribute__((aligned(16))) float red[4][8][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int u0 = blockIdx.x * 8;
+    const int kper = H / 4, kbeg = wave * kper;
+    const T* arow[4];
+    bool aok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = i * 16 + fr;
+        aok[i] = m < B;
+        arow[i] = h_prev + (int64_t)(aok[i] ? m : 0) * H + kbeg + fg * 8;
+    }
+    const T* brow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cj = 2 * fr + j;
+        brow[j] = wh + (int64_t)((cj >> 3) * H + u0 + (cj & 7)) * ldw + kbeg + fg * 8;
+    }
+    float v[4][2];
+    skinny_product<T>(arow, aok, brow, kper, red, v);
+    __syncthreads();                                   // every wave has read the partial tiles
+    float* tile = &red[0][0][0][0];                    // [64][33]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tile[(wave * 16 + fg * 4 + r) * 33 + 2 * fr + j] = v[r][j];
+    __syncthreads();
+    const int b = tid & 63;
+    if (b >= B) return;
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+        const int u = (tid >> 6) * 2 + uu;
+        T* gr = gates + (int64_t)b * 4 * H + u0 + u;
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const T stored = from_f32<T>(tile[b * 33 + 8 * g + u] + to_f32(gr[g * H]));
+            gr[g * H] = stored;                        // the pre-activation BPTT reads back
+            pre[g] = to_f32(stored);
+        }
+        const float i_ = sigmoid_for<T>(pre[0]), f_ = sigmoid_for<T>(pre[1]), o_ = sigmoid_for<T>(pre[2]), g_ = tanh_for<T>(pre[3]);
+        const float cp = c_prev ? to_f32(c_prev[(int64_t)b * H + u0 + u]) : 0.f;
+        const float cn = f_ * cp + i_ * g_;
+        c[(int64_t)b * H + u0 + u] = from_f32<T>(cn);
+        h[(int64_t)b * H + u0 + u] = from_f32<T>(o_ * tanh_for<T>(cn));
+    }
+}
+
+// backward step: dh_{t-1} = dh_in + dG_t . Wh (whT rows = hidden units, reduction over the 4H gates), then the
+// cell backward of step t-1 on the thread's own 4 x 2 outputs: dG_{t-1}, dc_{t-2}.
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const T* __restrict__ dg_t, const T* __restrict__ whT, int ldwT, const T* __restrict__ dh_in,
+                                                            const T* __restrict__ gates_p, const T* __restrict__ c_pp, const T* __restrict__ c_p,
+                                                            const T* __restrict__ dc_in, T* dg_p, T* dc_prev, int dc_prev_acc, int B, int H) {
+    __shared__ __attribute__((aligned(16))) float red[4][8][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 32;
+    const int kper = H, kbeg = wave * kper;            // reduction length 4H, a quarter per wave
+    const T* arow[4];
+    bool aok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = i * 16 + fr;
+        aok[i] = m < B;
+        arow[i] = dg_t + (int64_t)(aok[i] ? m : 0) * 4 * H + kbeg + fg * 8;
+    }
+    const T* brow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) brow[j] = whT + (int64_t)(n0 + 2 * fr + j) * ldwT + kbeg + fg * 8;
+    // the cell's operands do not depend on the product: load them first, their latency hides under it
+    typedef T __attribute__((ext_vector_type(2))) Pair;
+    Pair pg[4][4], pc[4], pcp[4], pdc[4], pdh[4];
+    const int col0 = n0 + 2 * fr;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = wave * 16 + fg * 4 + r;
+        const bool ok = row < B;
+        const int64_t e = (int64_t)(ok ? row : 0) * H + col0, ge = (int64_t)(ok ? row : 0) * 4 * H + col0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pg[r][g] = *reinterpret_cast<const Pair*>(gates_p + ge + g * H);
+        pc[r] = *reinterpret_cast<const Pair*>(c_p + e);
+        pcp[r] = c_pp ? *reinterpret_cast<const Pair*>(c_pp + e) : Pair{};
+        pdc[r] = dc_in ? *reinterpret_cast<const Pair*>(dc_in + e) : Pair{};
+        pdh[r] = dh_in ? *reinterpret_cast<const Pair*>(dh_in + e) : Pair{};
+    }
+    float v[4][2];
+    skinny_product<T>(arow, aok, brow, kper, red, v);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = wave * 16 + fg * 4 + r;
+        if (row >= B) continue;
+        const int64_t e = (int64_t)row * H + col0, ge = (int64_t)row * 4 * H + col0;
+        Pair odg[4], odc;
+        const Pair old_dc = (dc_prev && dc_prev_acc) ? *reinterpret_cast<const Pair*>(dc_prev + e) : Pair{};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float dhh = to_f32(from_f32<T>(v[r][j] + (float)pdh[r][j]));
+            const float i_ = sigmoid_for<T>((float)pg[r][0][j]), f_ = sigmoid_for<T>((float)pg[r][1][j]);
+            const float o_ = sigmoid_for<T>((float)pg[r][2][j]), g_ = tanh_for<T>((float)pg[r][3][j]);
+            const float tc = tanh_for<T>((float)pc[r][j]);
+            const float dct = (float)pdc[r][j] + dhh * o_ * (1.f - tc * tc);
+            const float cpv = (float)pcp[r][j];
+            odg[0][j] = from_f32<T>(dct * g_ * i_ * (1.f - i_));
+            odg[1][j] = from_f32<T>(dct * cpv * f_ * (1.f - f_));
+            odg[2][j] = from_f32<T>(dhh * tc * o_ * (1.f - o_));
+            odg[3][j] = from_f32<T>(dct * i_ * (1.f - g_ * g_));
+            odc[j] = from_f32<T>(dct * f_ + (float)old_dc[j]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<Pair*>(dg_p + ge + g * H) = odg[g];
+        if (dc_prev) *reinterpret_cast<Pair*>(dc_prev + e) = odc;
+    }
+}
+
+extern "C" int capmi_lstm_step_supported(int B, int H, int dtype) {
+    return (B >= 1 && B <= 64 && H >= 256 && H % 128 == 0 && (dtype == CAPMI_BF16 || dtype == CAPMI_F32)) ? 1 : 0;
+}
+extern "C" int capmi_lstm_step_fwd(const void* h_prev, const void* wh, int ldw, void* gates, const void* c_prev, void* h, void* c,
+                                   int B, int H, int dtype, void* stream) {
+    CAPMI_CHECK(h_prev && wh && gates && h && c, "capmi_lstm_step_fwd: null pointer");
+    CAPMI_CHECK(capmi_lstm_step_supported(B, H, dtype), "capmi_lstm_step_fwd: B=%d H=%d outside the fused kernel (B <= 64, H %% 128 == 0, H >= 256)", B, H);
+    const int vec = dtype == CAPMI_F32 ? 4 : 8;
+    CAPMI_CHECK(ldw % vec == 0, "capmi_lstm_step_fwd: ldw=%d must be a multiple of %d", ldw, vec);
+    if (dtype == CAPMI_BF16)
+        hipLaunchKernelGGL(lstm_step_fwd_kernel<bf16>, dim3(H / 8), dim3(256), 0, (hipStream_t)stream, (const bf16*)h_prev, (const bf16*)wh, ldw,
+                           (bf16*)gates, (const bf16*)c_prev, (bf16*)h, (bf16*)c, B, H);
+    else
+        hipLaunchKernelGGL(lstm_step_fwd_kernel<float>, dim3(H / 8), dim3(256), 0, (hipStream_t)stream, (const float*)h_prev, (const float*)wh, ldw,
+                           (float*)gates, (const float*)c_prev, (float*)h, (float*)c, B, H);
+    CAPMI_LAUNCH_CHECK("capmi_lstm_step_fwd");
+    return 0;
+}
+extern "C" int capmi_lstm_step_bwd(const void* dgates_t, const void* whT, int ldwT, const void* dh_in, const void* gates_prev,
+                                   const void* c_prev, const void* c, const void* dc_in, void* dgates_prev, void* dc_prev,
+                                   int dc_prev_accumulate, int B, int H, int dtype, void* stream) {
+    CAPMI_CHECK(dgates_t && whT && gates_prev && c && dgates_prev, "capmi_lstm_step_bwd: null pointer");
+    CAPMI_CHECK(capmi_lstm_step_supported(B, H, dtype), "capmi_lstm_step_bwd: B=%d H=%d outside the fused kernel", B, H);
+    const int vec = dtype == CAPMI_F32 ? 4 : 8;
+    CAPMI_CHECK(ldwT % vec == 0, "capmi_lstm_step_bwd: ldwT=%d must be a multiple of %d", ldwT, vec);
+    if (dtype == CAPMI_BF16)
+        hipLaunchKernelGGL(lstm_step_bwd_kernel<bf16>, dim3(H / 32), dim3(256), 0, (hipStream_t)stream, (const bf16*)dgates_t, (const bf16*)whT, ldwT,
+                           (const bf16*)dh_in, (const bf16*)gates_prev, (const bf16*)c_prev, (const bf16*)c, (const bf16*)dc_in, (bf16*)dgates_prev,
+                           (bf16*)dc_prev, dc_prev_accumulate, B, H);
+    else
+        hipLaunchKernelGGL(lstm_step_bwd_kernel<float>, dim3(H / 32), dim3(256), 0, (hipStream_t)stream, (const float*)dgates_t, (const float*)whT, ldwT,
+                           (const float*)dh_in, (const float*)gates_prev, (const float*)c_prev, (const float*)c, (const float*)dc_in, (float*)dgates_prev,
+                           (float*)dc_prev, dc_prev_accumulate, B, H);
+    CAPMI_LAUNCH_CHECK("capmi_lstm_step_bwd");
+    return 0;
+}
+
 struct NtCfg { int bm, bn, wmw; };
 static NtCfg nt_cfg(int M, int N, int K, int dtype) {
     const bool wide = N > 64;

@@ -12,9 +12,11 @@ time-major (m = t*B + b) so a timestep is a contiguous row block.  Per step only
 [B,H]x[H,4H] recurrent GEMM (accumulated onto the precomputed input gates in its epilogue)
 and the pointwise cell remain.  BPTT mirrors it.
 """
+import os
+
 import torch
 
-from ._lib import ACT_NONE, ACT_RELU, ACT_TANH, WGRAD_WS_BYTES, Plan, gemm_geom, wgrad_workspace
+from ._lib import lib, ACT_NONE, ACT_RELU, ACT_TANH, WGRAD_WS_BYTES, Plan, gemm_geom, wgrad_workspace
 from .params import FC
 
 
@@ -27,6 +29,8 @@ def vocab_ld(V):
 
 
 class DecoderRunner:
+    fuse_lstm = True        # recurrent product + cell in one launch per step where capmi_lstm_step_supported
+
     def __init__(self, store, B, K, T, dtype_code, torch_dtype, slots, need_backward=True):
         self.overlap_wgrad = True       # parameter-gradient launches of the backward plan go to the side lane
         self._sync_at = 0
@@ -168,8 +172,13 @@ class DecoderRunner:
         ldl = E + 2 * H
         self._gemm(plan, _p(self.X), M, E + H, _p(lw), 4 * H, _p(self.G), ldw=ldl, bias=_p(st.view('lstm_b')))
         wh = _p(lw) + (E + H) * es
+        fused = self.fuse_lstm and os.environ.get('CAPMI_LSTM_FUSE', '1') != '0' and bool(lib().capmi_lstm_step_supported(B, H, code))   # one launch per step
         for t in range(T):                                                                                        # :75-127
             Gt = _p(self.G) + t * B * 4 * H * es
+            if t > 0 and fused:
+                plan.add('capmi_lstm_step_fwd', _p(self.Hbuf) + t * B * H * es, wh, ldl, Gt, _p(self.Cbuf) + t * B * H * es,
+                         _p(self.Hbuf) + (t + 1) * B * H * es, _p(self.Cbuf) + (t + 1) * B * H * es, B, H, code)
+                continue
             if t > 0:     # h_{-1} = 0 (:63): nothing to add at t = 0
                 self._gemm(plan, _p(self.Hbuf) + t * B * H * es, B, H, wh, 4 * H, Gt, ldw=ldl, addend=Gt, ld_add=4 * H)
             plan.add('capmi_lstm_cell_fwd', Gt, _p(self.Cbuf) + t * B * H * es, _p(self.Hbuf) + (t + 1) * B * H * es,
@@ -250,13 +259,21 @@ class DecoderRunner:
         # BPTT through the lstm_unit (:87-88)
         lwT = WT('lstm_w')                       # [E+2H][4H]
         whT = _p(lwT) + (E + H) * 4 * H * es
+        # measured at cfg 2: the fused forward step wins (10.8 us vs 15.7 + 5.2), the fused backward step (16 workgroups
+        # carrying the whole cell backward) loses to product + cell (18-29 us vs 7.9 + 6.0): forward only by default
+        fused = self.fuse_lstm and os.environ.get('CAPMI_LSTM_FUSE', '1') == '2' and bool(lib().capmi_lstm_step_supported(B, H, code))
         for t in reversed(range(T)):
             blk = lambda buf, i: _p(buf) + i * B * H * es
             Gt = _p(self.G) + t * B * 4 * H * es
             dGt = _p(self.dG) + t * B * 4 * H * es
-            plan.add('capmi_lstm_cell_bwd', Gt, blk(self.Cbuf, t), blk(self.Cbuf, t + 1), blk(self.dHbuf, t + 1),
-                     blk(self.dCbuf, t + 1), dGt, blk(self.dCbuf, t) if t > 0 else None, 1, B, H, code)
-            if t > 0:
+            if not fused or t == T - 1:
+                plan.add('capmi_lstm_cell_bwd', Gt, blk(self.Cbuf, t), blk(self.Cbuf, t + 1), blk(self.dHbuf, t + 1),
+                         blk(self.dCbuf, t + 1), dGt, blk(self.dCbuf, t) if t > 0 else None, 1, B, H, code)
+            if t > 0 and fused:
+                # dh_{t-1} += dG_t . Wh and the cell backward of step t-1 in one launch
+                plan.add('capmi_lstm_step_bwd', dGt, whT, 4 * H, blk(self.dHbuf, t), Gt - B * 4 * H * es, blk(self.Cbuf, t - 1), blk(self.Cbuf, t),
+                         blk(self.dCbuf, t), dGt - B * 4 * H * es, blk(self.dCbuf, t - 1) if t > 1 else None, 1, B, H, code)
+            elif t > 0:
                 self._gemm(plan, dGt, B, 4 * H, whT, H, blk(self.dHbuf, t), addend=blk(self.dHbuf, t), ld_add=H)
         ldl = E + 2 * H
         self._wgrad(plan, _p(self.X), M, E + H, _p(self.dG), 4 * H, g_('lstm_w'), lddw=ldl)

@@ -493,6 +493,53 @@ def test_lstm_cell_sentinel_embedding(dtype):
     check(host(DT), O.embedding_bwd(dout[:, :E], ids, (V, E), 0), dtype, name='embedding bwd')
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('B,H,E', [(64, 256, 128), (5, 384, 40)])
+def test_fused_lstm_steps_equal_product_plus_cell(dtype, B, H, E):
+    """capmi_lstm_step_{fwd,bwd} (recurrent product + cell in one launch) against the two-launch form they replace
+    (capmi_igemm_nt + capmi_lstm_cell_*): same arithmetic and rounding points (the stored gate pre-activations are
+    bit-identical; the cell may differ by FMA contraction, i.e. an ulp); the two-launch form is pinned against the
+    oracle by test_lstm_cell_sentinel_embedding and the GEMM tests."""
+    _lib, tdt, code = _env()
+    assert _lib.lib().capmi_lstm_step_supported(B, H, code[dtype]) == 1
+    rng = np.random.RandomState(B + H)
+    ld = E + 2 * H
+    lw = dev(rng.standard_normal((4 * H, ld)) / np.sqrt(H), tdt[dtype])           # lstm_w kernel layout [4H][E+H | H]
+    es = lw.element_size()
+    wh = lw.data_ptr() + (E + H) * es
+    hp, cp = dev(rng.standard_normal((B, H)) * 0.5, tdt[dtype]), dev(rng.standard_normal((B, H)) * 0.5, tdt[dtype])
+    gin = dev(rng.standard_normal((B, 4 * H)), tdt[dtype])
+    # forward
+    g1, g2 = gin.clone(), gin.clone()
+    h1, c1, h2, c2 = (torch.zeros((B, H), dtype=tdt[dtype], device=DEV) for _ in range(4))
+    _KEEP.extend([g1, g2, h1, c1, h2, c2])
+    _lib.call('capmi_igemm_nt', p(hp), wh, p(g1), _lib.gemm_geom(B, H), 4 * H, ld, 4 * H, None, p(g1), 4 * H, None, 0, None, 0, 0, 0, code[dtype], stream())
+    _lib.call('capmi_lstm_cell_fwd', p(g1), p(cp), p(h1), p(c1), B, H, code[dtype], stream())
+    _lib.call('capmi_lstm_step_fwd', p(hp), wh, ld, p(g2), p(cp), p(h2), p(c2), B, H, code[dtype], stream())
+    torch.cuda.synchronize()
+    tol = dict(rtol=1e-5, atol=1e-6) if dtype == 'f32' else dict(rtol=8e-3, atol=1e-3)
+    close = lambda x, y: torch.allclose(x.float(), y.float(), **tol)
+    assert torch.equal(g1, g2) and close(c1, c2) and close(h1, h2)
+    # backward: dh_{t-1} += dG_t . Wh, then the cell backward of step t-1
+    whT = dev(rng.standard_normal((H, 4 * H)) / np.sqrt(H), tdt[dtype])
+    dgt = dev(rng.standard_normal((B, 4 * H)) * 0.1, tdt[dtype])
+    dh0 = dev(rng.standard_normal((B, H)) * 0.1, tdt[dtype])
+    dcin = dev(rng.standard_normal((B, H)) * 0.1, tdt[dtype])
+    dcp0 = dev(rng.standard_normal((B, H)) * 0.1, tdt[dtype])
+    for cprev, acc in ((cp, 1), (None, 0)):
+        dh1 = dh0.clone()
+        dg1, dg2 = (torch.zeros((B, 4 * H), dtype=tdt[dtype], device=DEV) for _ in range(2))
+        dcp1, dcp2 = dcp0.clone(), dcp0.clone()
+        _KEEP.extend([dh1, dg1, dg2, dcp1, dcp2])
+        _lib.call('capmi_igemm_nt', p(dgt), p(whT), p(dh1), _lib.gemm_geom(B, 4 * H), H, 4 * H, H, None, p(dh1), H, None, 0, None, 0, 0, 0,
+                  code[dtype], stream())
+        _lib.call('capmi_lstm_cell_bwd', p(g1), p(cprev), p(c1), p(dh1), p(dcin), p(dg1), p(dcp1), acc, B, H, code[dtype], stream())
+        _lib.call('capmi_lstm_step_bwd', p(dgt), p(whT), 4 * H, p(dh0), p(g1), p(cprev), p(c1), p(dcin), p(dg2), p(dcp2), acc, B, H,
+                  code[dtype], stream())
+        torch.cuda.synchronize()
+        assert close(dg1, dg2) and close(dcp1, dcp2)
+
+
 def _attn_ref(Ve, Vt, q, se, s, pp, w10, b10, T, B, K, H, slots):
     """Oracle of one attention call, rows time-major; returns out, alpha."""
     M = T * B

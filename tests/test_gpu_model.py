@@ -245,3 +245,37 @@ def test_side_stream_weight_gradients_match_single_stream(monkeypatch):
         grads.append(eng.store.grad[:eng.store.trainable_size].double().cpu().numpy().copy())
     scale = np.abs(grads[0]).max()
     assert np.abs(grads[0] - grads[1]).max() <= 1e-5 * scale
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_train_step_with_fused_lstm_steps(dtype, monkeypatch):
+    """hidden = 256 takes the fused recurrence kernels (capmi_lstm_step_*): f32 against the oracle at the tolerances
+    of the two-launch path; both dtypes against the same engine with the fusion switched off."""
+    from myimagecaptioningmodel_amd import _lib
+    from myimagecaptioningmodel_amd.decoder import DecoderRunner
+    monkeypatch.setenv('CAPMI_LSTM_FUSE', '2')          # both directions (the default fuses the forward step only)
+    ocfg, ecfg = _cfgs('mobilenetv2', 'slots', dtype, S=64, H=256, E=64, V=60, L=5)
+    params, image, caption = _data(ocfg, 4, 21)
+    eng = _engine(ecfg, params)
+    assert _lib.lib().capmi_lstm_step_supported(4, 256, eng.code) == 1
+    le = float(eng.forward_backward(image, caption).cpu()[0])
+    assert any(n == 'capmi_lstm_step_fwd' for _, n, _ in eng._train[4]['fwd'].launches())
+    assert any(n == 'capmi_lstm_step_bwd' for _, n, _ in eng._train[4]['bwd'].launches())
+    ge = eng.export_reference_grads()
+    monkeypatch.setattr(DecoderRunner, 'fuse_lstm', False)
+    ref = _engine(ecfg, params)
+    lr = float(ref.forward_backward(image, caption).cpu()[0])
+    assert not any(n == 'capmi_lstm_step_fwd' for _, n, _ in ref._train[4]['fwd'].launches())
+    gr = ref.export_reference_grads()
+    a = np.concatenate([ge[k].ravel() for k in sorted(ge)])
+    b = np.concatenate([gr[k].ravel() for k in sorted(gr)])
+    tol = 1e-5 if dtype == 'f32' else 2e-2
+    assert abs(le - lr) <= tol and np.linalg.norm(a - b) <= (1e-4 if dtype == 'f32' else 5e-2) * np.linalg.norm(b)
+    if dtype == 'f32':
+        o = om.OracleModel(ocfg, params)
+        lo, _ = o.forward_train(image, caption, update_stats=False)
+        go = o.backward()
+        assert abs(le - lo) <= 1e-4
+        num = np.sqrt(sum(np.sum((ge[k] - go[k]) ** 2) for k in go))
+        den = np.sqrt(sum(np.sum(go[k] ** 2) for k in go))
+        assert num <= 2e-3 * den, num / den
