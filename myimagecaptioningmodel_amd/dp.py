@@ -10,8 +10,9 @@ statistics stay per rank.
 The flat gradient buffer is ordered in backward-completion order (params.py), so a bucket is a
 contiguous slice.  `GradBuckets` cuts it at parameter boundaries into ~bucket_bytes pieces;
 `OverlappedTrainer` replays backward in segments and launches each bucket's all-reduce on a
-side stream as soon as its segment has been enqueued, so xGMI traffic hides under the remaining
-encoder backward.  xGMI is point-to-point (7 links per GPU), ring all-reduce time is set by one
+side stream as soon as its segment has been enqueued -- and Adam + the weight-shadow refresh of the bucket
+right behind it on the same stream -- so xGMI traffic and the optimizer hide under the remaining encoder
+backward.  xGMI is point-to-point (7 links per GPU), ring all-reduce time is set by one
 link, hence few large buckets (default 32 MiB) rather than per-tensor calls.
 """
 import os
@@ -75,7 +76,9 @@ class OverlappedTrainer:
     Backward is cut where a bucket of the flat gradient buffer becomes final (after the decoder,
     then after encoder layers from last to first); each segment is its own hipGraph.  After a
     segment is enqueued, an event is recorded on the compute stream and the bucket's all-reduce is
-    issued on a side stream behind that event; Adam waits for the side stream."""
+    issued on a side stream behind that event, followed on the same stream by Adam and the shadow refresh of
+    that bucket's parameters (`CaptionEngine.optimizer_range`): the optimizer, too, runs under the remaining
+    backward pass; the next forward waits for the side stream."""
 
     def __init__(self, engine, bucket_bytes=32 << 20):
         self.eng = engine
@@ -122,9 +125,14 @@ class OverlappedTrainer:
         if eng.shadows_dirty:
             eng.refresh_shadows()
         eng._feed_train(prog, image, caption)
+        from .optim import adam_lr_t
         cur = torch.cuda.current_stream(eng.device)
         eng._run_captured(P['fwd_graph'], 'g', prog['fwd_parts'] if eng.graph_decoder_forward else [prog['fwd']])
         grad = eng.store.grad
+        lr = eng.lr_schedule.value(eng.step_count)
+        eng.step_count += 1
+        lr_t = adam_lr_t(lr, eng.step_count)
+        total = eng.store.trainable_size
         for sub, (b, e), holder in P['segs']:
             eng._run_captured(holder, 'g', [sub])
             ev = torch.cuda.Event()
@@ -132,7 +140,9 @@ class OverlappedTrainer:
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
                 dist.all_reduce(grad[b:e], op=dist.ReduceOp.SUM, group=eng.pg)
+                # the bucket's parameters are final for this step: Adam + shadow refresh right behind its
+                # all-reduce, on the communication stream, under the rest of the backward pass
+                eng.optimizer_range(b, e, lr_t, self.comm_stream.cuda_stream, tail=(e == total))
         cur.wait_stream(self.comm_stream)
-        lr = eng.optimizer_step()
-        eng.refresh_shadows()
+        eng.shadows_dirty = False
         return prog['dec'].loss, lr

@@ -299,6 +299,23 @@ class CaptionEngine:
         self.shadows_dirty = True
         return lr
 
+    def optimizer_range(self, b, e, lr_t, stream, tail=False):
+        """Adam + shadow refresh of flat range [b, e) on `stream` (a raw HIP stream): what optimizer_step +
+        refresh_shadows do for the whole buffer, for one all-reduce bucket.  tail=True also refreshes the
+        shadows of everything behind e (non-trainable state)."""
+        st, cfg = self.store, self.cfg
+        clip = float(cfg['gradient_clip']) if cfg.get('gradient_clip') else 0.0
+        if e > b:
+            _lib.call('capmi_adam', st.flat.data_ptr() + b * 4, st.grad.data_ptr() + b * 4, st.adam_m.data_ptr() + b * 4,
+                      st.adam_v.data_ptr() + b * 4, e - b, lr_t, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, 1.0 / self.world, stream)
+        hi = st.size if tail else e
+        if self.low is not None and hi > b:
+            _lib.call('capmi_cast', st.flat.data_ptr() + b * 4, self.low.data_ptr() + b * self.low.element_size(), hi - b, self.code, stream)
+        j0 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= b), len(self.dgrad_job_src))
+        j1 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= hi), len(self.dgrad_job_src))
+        if j1 > j0:
+            _lib.call('capmi_weight_dgrad_form_batched', _p(st.flat), _p(self.wT), self.dgrad_jobs.data_ptr() + j0 * 56, j1 - j0, self.code, stream)
+
     def allreduce_grads(self):
         """Sum of the per-rank gradients (ParallelExecutor's AllReduce strategy, IC/train.py:121-124);
         the 1/N CoeffNumDevice scale is applied inside the Adam kernel."""
