@@ -16,7 +16,7 @@ import os
 
 import torch
 
-from ._lib import lib, ACT_NONE, ACT_RELU, ACT_TANH, WGRAD_WS_BYTES, Plan, gemm_geom, wgrad_workspace
+from ._lib import lib, ACT_NONE, ACT_RELU, ACT_TANH, WGRAD_WS_BYTES, gemm_geom, wgrad_workspace
 from .params import FC
 
 

@@ -13,7 +13,7 @@ weight-gradient GEMM (split over pixels, f32 atomics) -> data-gradient GEMM.
 import torch
 
 from . import arch
-from ._lib import ACT_CODES, WGRAD_WS_BYTES, ConvGeom, NtCall, Plan, gemm_geom, lib, wgrad_workspace
+from ._lib import ACT_CODES, WGRAD_WS_BYTES, ConvGeom, NtCall, lib, wgrad_workspace
 from .params import stem_s2d
 
 BN_MOMENTUM = 0.9      # fluid.layers.batch_norm defaults; MobileNetV2.py:112-117 overrides neither

@@ -10,7 +10,7 @@ import ctypes
 
 import torch
 
-from ._lib import BF16, ConvGeom
+from ._lib import BF16
 
 # Peaks used as roofline denominators (/opt/skills/guides/MI355X_MICROARCH.md, chip-level table)
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec; ~6300 measured achievable
