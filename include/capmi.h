@@ -173,6 +173,14 @@ int capmi_bn_finalize(float* ws, int part_rows, int M, int C, const float* scale
                       int update_running, void* stream);
 int capmi_bn_apply(const void* x, const float* saved_mean, const float* coef_a, const float* offset,
                    const void* res, void* y, int M, int C, int act, int dtype, void* stream);
+/* capmi_bn_finalize + capmi_bn_apply in ONE launch (plus the merge launch for > 64 parts): every apply workgroup
+ * merges the statistic groups of its own channels (f64, Chan) before normalising its rows; saved mean / invstd and
+ * the running statistics are written by the first workgroup row.  Same results as the two calls.  Measured
+ * SLOWER in the model (-6 %: the per-workgroup merge delays every workgroup's first load by more than the
+ * saved launch); the engine uses capmi_bn_finalize + capmi_bn_apply. */
+int capmi_bn_finalize_apply(float* ws, int part_rows, int M, int C, const float* scale, const float* offset, float* run_mean,
+                            float* run_var, float momentum, float eps, float* saved_mean, float* saved_invstd,
+                            int update_running, const void* x, const void* res, void* y, int act, int dtype, void* stream);
 int capmi_bn_bwd_ws_floats(int M, int C, int dtype);
 int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y, const float* saved_mean,
                         const float* saved_invstd, float* ws, float* red, int M, int C, int act,

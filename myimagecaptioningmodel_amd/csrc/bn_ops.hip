@@ -166,6 +166,128 @@ extern "C" int capmi_bn_finalize(float* ws, int part_rows, int M, int C, const f
     return 0;
 }
 
+// ------------------------------------------------------------------ finalize + apply in one launch
+// The forward critical path per layer was conv -> (merge) -> finalize -> apply: the finalize kernel is ~6 us of
+// pure latency.  Here every apply workgroup merges the (<= 64) statistic groups of ITS channels itself
+// (the lanes that share a channel chunk split the groups, Chan's formula in f64 through LDS) and goes straight
+// on to normalise its rows; workgroup row 0 also stores the saved mean / invstd and updates the running stats.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __restrict__ ws, int part_rows, int nparts, int M, int C,
+                                                                const float* __restrict__ scale, const float* __restrict__ offset,
+                                                                float* run_mean, float* run_var, float momentum, float eps,
+                                                                float* saved_mean, float* saved_invstd, int update_running,
+                                                                const T* __restrict__ x, const T* __restrict__ res, T* __restrict__ y,
+                                                                int act, ColLayout L) {
+    constexpr int VEC = Vec<T>::N;
+    __shared__ double part[256 * VEC];
+    const int cc = threadIdx.x % L.cpc, rr = threadIdx.x / L.cpc;
+    const int chunk = blockIdx.y * L.cpc + cc;
+    const bool active = rr < L.rp && chunk * VEC < C;
+    // pass 1: weighted mean of the group means
+    double s[VEC], cnt = 0.0;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = 0.0;
+    if (active)
+        for (int p = rr; p < nparts; p += L.rp) {
+            const double n = (double)min(part_rows, M - p * part_rows);
+            const float* w = ws + ((int64_t)p * C + chunk * VEC) * 2;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) s[v] += n * (double)w[2 * v];
+            cnt += n;
+        }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) part[(rr * L.cpc + cc) * VEC + v] = s[v];
+    __syncthreads();
+    double mean[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        double t = 0.0;
+        for (int r2 = 0; r2 < L.rp; ++r2) t += part[(r2 * L.cpc + cc) * VEC + v];
+        mean[v] = t / (double)M;
+    }
+    __syncthreads();
+    // pass 2: M2 = sum_p M2_p + n_p (mean_p - mean)^2
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) s[v] = 0.0;
+    if (active)
+        for (int p = rr; p < nparts; p += L.rp) {
+            const double n = (double)min(part_rows, M - p * part_rows);
+            const float* w = ws + ((int64_t)p * C + chunk * VEC) * 2;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const double d = (double)w[2 * v] - mean[v];
+                s[v] += (double)w[2 * v + 1] + n * d * d;
+            }
+        }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) part[(rr * L.cpc + cc) * VEC + v] = s[v];
+    __syncthreads();
+    if (!active) return;
+    float a[VEC], bo[VEC], mu[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        double m2 = 0.0;
+        for (int r2 = 0; r2 < L.rp; ++r2) m2 += part[(r2 * L.cpc + cc) * VEC + v];
+        const int c = chunk * VEC + v;
+        const double var = m2 / (double)M;      // biased
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        mu[v] = (float)mean[v];
+        a[v] = scale[c] * invstd;
+        bo[v] = offset[c];
+        if (blockIdx.x == 0 && rr == 0) {
+            saved_mean[c] = mu[v];
+            saved_invstd[c] = invstd;
+            if (update_running) {
+                run_mean[c] = run_mean[c] * momentum + mu[v] * (1.f - momentum);
+                run_var[c] = run_var[c] * momentum + (float)var * (1.f - momentum);
+            }
+        }
+    }
+    const int m_begin = blockIdx.x * L.rows_per_block;
+    const int m_end = min(M, m_begin + L.rows_per_block);
+#pragma unroll 8
+    for (int m = m_begin + rr; m < m_end; m += L.rp) {
+        const int64_t off = (int64_t)m * C + chunk * VEC;
+        Vec<T> xv = vload<T>(x + off), rv, ov;
+        if (res) rv = vload<T>(res + off);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float f = a[v] * (xv.get(v) - mu[v]) + bo[v];
+            if (res) f += rv.get(v);
+            ov.set(v, apply_act(f, act));
+        }
+        vstore<T>(y + off, ov);
+    }
+}
+
+extern "C" int capmi_bn_finalize_apply(float* ws, int part_rows, int M, int C, const float* scale, const float* offset, float* run_mean,
+                                       float* run_var, float momentum, float eps, float* saved_mean, float* saved_invstd,
+                                       int update_running, const void* x, const void* res, void* y, int act, int dtype, void* stream) {
+    CAPMI_CHECK(ws && scale && offset && saved_mean && saved_invstd && x && y, "capmi_bn_finalize_apply: null pointer");
+    CAPMI_CHECK(part_rows > 0 && M > 0, "capmi_bn_finalize_apply: bad part_rows/M");
+    CAPMI_CHECK(!update_running || (run_mean && run_var), "capmi_bn_finalize_apply: running stats missing");
+    int nparts = cdiv(M, part_rows);
+    const float* src = ws;
+    int rows = part_rows;
+    if (nparts > 2 * CAPMI_BN_MERGE_GROUPS) {
+        const int k = cdiv(nparts, CAPMI_BN_MERGE_GROUPS);
+        float* merged = ws + (int64_t)nparts * C * 2;
+        hipLaunchKernelGGL(bn_merge_kernel, dim3(cdiv(C, 64), cdiv(nparts, k)), dim3(256), 0, (hipStream_t)stream, ws, part_rows, M, C, k, merged);
+        src = merged;
+        rows = part_rows * k;
+        nparts = cdiv(M, rows);
+    }
+    CAPMI_DISPATCH(dtype, "capmi_bn_finalize_apply", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_finalize_apply: C=%d not a multiple of %d", C, Vec<T>::N);
+        int gx, gy;
+        ColLayout L = ew_layout(M, C, Vec<T>::N, &gx, &gy, 64);      // <= 64 chunk columns: >= 4 lanes share a chunk's groups
+        hipLaunchKernelGGL(bn_finalize_apply_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, rows, nparts, M, C, scale, offset,
+                           run_mean, run_var, momentum, eps, saved_mean, saved_invstd, update_running, (const T*)x, (const T*)res, (T*)y, act, L);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bn_finalize_apply");
+    return 0;
+}
+
 // ------------------------------------------------------------------ apply: y = act(a*(x - mean) + offset (+ res))
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ ca,

@@ -220,10 +220,10 @@ __device__ __forceinline__ void block_col_reduce(float* part, float (&acc)[VEC],
 }
 
 // rows-per-thread-heavy variant of col_layout for the streaming (elementwise / reduce) kernels
-static ColLayout ew_layout(int M, int C, int vec, int* grid_x, int* grid_y) {
+static ColLayout ew_layout(int M, int C, int vec, int* grid_x, int* grid_y, int max_cpc = 256) {
     ColLayout L;
     int chunks = C / vec;
-    L.cpc = chunks < 256 ? chunks : 256;
+    L.cpc = chunks < max_cpc ? chunks : max_cpc;
     *grid_y = cdiv(chunks, L.cpc);
     L.rp = 256 / L.cpc;
     int target_blocks = 1024 / *grid_y;                 // ~4 workgroups per CU

@@ -103,6 +103,9 @@ def describe(name, args):
     if name == 'capmi_bn_apply':
         M, C, code = args[6], args[7], args[9]
         return 'bn_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[4] else 2)
+    if name == 'capmi_bn_finalize_apply':
+        M, C, code = args[2], args[3], args[17]
+        return 'bn_finalize_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[14] else 2)
     if name == 'capmi_bn_stats':
         return 'bn_stats_kernel', 0.0, args[1] * args[2] * es_of(args[4])
     if name == 'capmi_bn_bwd_reduce':

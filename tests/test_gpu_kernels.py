@@ -392,6 +392,17 @@ def test_batch_norm_chain(dtype, act, res):
     ac = _lib.ACT_CODES[act]
     _lib.call('capmi_bn_apply', p(X), p(mean), p(ca), p(OF), p(R), p(Y), M, C, ac, code[dtype], stream())
     check(host(Y), _nhwc(out), dtype, name='bn apply')
+    # the one-launch form (statistics merge inside the apply kernel) gives the same output, saved statistics and running stats
+    RM2, RV2 = dev(rm, f32), dev(rv, f32)
+    mean2, invstd2 = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(2))
+    Y2 = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+    _KEEP.extend([mean2, invstd2, Y2])
+    _lib.call('capmi_bn_finalize_apply', p(stats), pr, M, C, p(SC), p(OF), p(RM2), p(RV2), 0.9, 1e-5, p(mean2), p(invstd2), 1,
+              p(X), p(R), p(Y2), ac, code[dtype], stream())
+    torch.cuda.synchronize()
+    assert torch.allclose(mean2, mean, rtol=1e-6, atol=1e-7) and torch.allclose(invstd2, invstd, rtol=1e-6, atol=0)
+    assert torch.allclose(RM2, RM, rtol=1e-6, atol=1e-7) and torch.allclose(RV2, RV, rtol=1e-6, atol=1e-7)
+    check(host(Y2), _nhwc(out), dtype, name='bn finalize+apply')
     # backward uses the stored (rounded) output for the activation mask, as the engine does
     Yexact = dev(_nhwc(out), tdt[dtype])
     DY = dev(_nhwc(dout), tdt[dtype])
