@@ -771,6 +771,10 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         for (int i = 0; i < TM; ++i) af[i].load(reinterpret_cast<const T*>(st + aoff[i]));
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j].load(reinterpret_cast<const T*>(st + boff[j]));
+        // every fragment read is issued before the first MFMA: one exposed LDS latency per k-step instead of one
+        // per pair of MFMAs (the scheduler otherwise recycles two fragment registers; grids below ~2 waves per
+        // SIMD have nobody to hide that behind)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
