@@ -10,6 +10,8 @@ Activations are NHWC in HBM, so the encoder output [B, S/32, S/32, C] already IS
 (model_adaAttention_aic.py:193-195).  Backward mirrors it: bn_bwd_reduce -> bn_bwd_apply ->
 weight-gradient GEMM (split over pixels, f32 atomics) -> data-gradient GEMM.
 """
+import os
+
 import torch
 
 from . import arch
@@ -129,8 +131,8 @@ class EncoderRunner:
             elif isinstance(op, arch.MaxPool):
                 self.pool_idx[op.dst] = z((B, h, w, c), torch.uint8)
         # grad w.r.t. a conv's raw output: a ring of scratch buffers, so that the weight gradient of layer L
-        # (side lane) can still read its buffer while the main lane already produces the one of layer L-1
-        self.draws = [z((max_elems,)) for _ in range(3)] if need_backward else None
+        # (side lane) can still read its buffer while the main lane already produces the ones of the next layers
+        self.draws = [z((max_elems,)) for _ in range(int(os.environ.get('CAPMI_RING', '6')))] if need_backward else None
         self.draw = self.draws[0] if need_backward else None
         self.overlap_wgrad = True
         self.overlap_forward = True     # projection shortcuts of the forward pass on the side lane
