@@ -653,7 +653,10 @@ __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BM, int BN, int NST, bool RED, int LIN>
+// KG = 2: eight waves, two k-groups -- group g takes the k-steps s with s % 2 == g (its own half of every ring slot)
+// and the groups' accumulators meet in LDS before the epilogue.  Same tile, same bytes, twice the waves: for
+// deep-K layers whose grid is below ~2 workgroups per CU the loop is bound by per-wave latency, not by MFMA.
+template <int BM, int BN, int NST, bool RED, int LIN, int KG = 1>
 __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int nblocks) {
     typedef bf16 T;
     constexpr int BK = 32, WMW = 4;
@@ -662,11 +665,12 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     constexpr int STB = AOPB + BOPB;                    // bytes per stage
     constexpr int ACNT = BM / 64, BCNT = BN / 64;       // DMA instructions per thread per stage
     constexpr int NGL = ACNT + BCNT;
-    __shared__ __attribute__((aligned(1024))) char smem[NST * STB < 4096 ? 4096 : NST * STB];
+    __shared__ __attribute__((aligned(1024))) char smem[NST * KG * STB < 4096 ? 4096 : NST * KG * STB];
 
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ W = (const T*)a.w;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);       // k-group of this wave
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // position inside the group
     const int tiles_n = (a.N + BN - 1) / BN;
     const int tile = xcd_swizzle(block, nblocks);
     const int m0 = (tile / tiles_n) * BM;
@@ -688,7 +692,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         wok[i] = n < a.N;
         wrow[i] = W + (int64_t)(wok[i] ? n : 0) * a.ldw;
     }
-    KPos kp = k_pos(chunk * 8, a.g);
+    KPos kp = k_pos(chunk * 8 + grp * BK, a.g);
     const T* zero = reinterpret_cast<const T*>(capmi_zero_page);
     // addressing mode LIN: 1 = 1x1 / no padding (any stride): A(m, k) = x[base(m) + k], no tap arithmetic in the
     // loop; 2 = up == 1 and Cin >= BK: taps tracked with selects, no branches; 0 = general (a_offset)
@@ -697,7 +701,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     for (int i = 0; i < ACNT; ++i) arow[i] = rp[i].ok ? X + rp[i].base : nullptr;
     const int Hi = a.g.Hi, Wi = a.g.Wi, ldx = a.g.ldx, Cin = a.g.Cin, kw = a.g.kw;
     auto issue_stage = [&](int st) {    // DMA of the tile at the current kp into ring slot st; advances kp
-        char* base = smem + st * STB + wave * 1024;
+        char* base = smem + (st * KG + grp) * STB + wave * 1024;
 #pragma unroll
         for (int i = 0; i < ACNT; ++i) {
             const T* src;
@@ -721,17 +725,17 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + AOPB + i * 4096), 16, 0, 0);
         }
-        if constexpr (LIN == 1) kp.k += BK;
-        else if constexpr (LIN == 2) {       // Cin >= BK: one channel wrap at most per step
-            kp.k += BK;
-            kp.c += BK;
+        if constexpr (LIN == 1) kp.k += KG * BK;
+        else if constexpr (LIN == 2) {       // Cin >= KG*BK: one channel wrap at most per step
+            kp.k += KG * BK;
+            kp.c += KG * BK;
             const bool wc = kp.c >= Cin;
             kp.c -= wc ? Cin : 0;
             kp.q += wc ? 1 : 0;
             const bool wq = kp.q == kw;
             kp.q = wq ? 0 : kp.q;
             kp.r += wq ? 1 : 0;
-        } else k_advance(kp, BK, a.g);
+        } else k_advance(kp, KG * BK, a.g);
     };
 
     f32x4 acc[TM][TN];
@@ -740,7 +744,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (a.K + BK - 1) / BK;
+    const int nkt = (a.K + KG * BK - 1) / (KG * BK);
     const int fr = lane & 15, fg = lane >> 4;
     // fragment byte offsets inside a stage (swizzled chunk position)
     int aoff[TM], boff[TN];
@@ -764,7 +768,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         __builtin_amdgcn_s_barrier();                        // ... and everyone else's; all waves left stage kt-1
         asm volatile("" ::: "memory");
         issue_stage(slot == 0 ? NST - 1 : slot - 1);         // refill the slot that was read in iteration kt-1
-        const char* st = smem + slot * STB;
+        const char* st = smem + (slot * KG + grp) * STB;
         slot = slot + 1 == NST ? 0 : slot + 1;
         Frag<T> af[TM], bf[TN];
 #pragma unroll
@@ -782,12 +786,35 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the (zero-page) tail stages before LDS reuse
     __syncthreads();
+    if constexpr (KG == 2) {            // group 1 hands its accumulators over and leaves; group 0 runs the epilogue
+        f32x4* xch = reinterpret_cast<f32x4*>(smem);
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) xch[(i * TN + j) * 256 + tid] = acc[i][j];
+        }
+        __syncthreads();
+        if (grp == 1) {                 // keep the barrier count of the epilogue's statistics path (two), then leave
+            if (a.stats) { __syncthreads(); __syncthreads(); }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += xch[(i * TN + j) * 256 + tid];
+    }
     nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
 }
 
 template <int BM, int BN, int NST, bool RED = false, int LIN = 0>
 __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_kernel(IGemmArgs a) {
     nt_glds_body<BM, BN, NST, RED, LIN>(a, blockIdx.x, gridDim.x);
+}
+
+template <int BM, int BN, int NST, int LIN>
+__global__ __launch_bounds__(512, 2) void igemm_nt_glds_k2_kernel(IGemmArgs a) {
+    nt_glds_body<BM, BN, NST, false, LIN, 2>(a, blockIdx.x, gridDim.x);
 }
 
 // Several independent problems (the parity classes of a strided data gradient) in ONE launch: the
@@ -1225,7 +1252,10 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
     do {                                                                                                                      \
         const int64_t tiles = (int64_t)cdiv(a.M, BM_) * cdiv(a.N, BN_);                                                       \
         CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");                                                   \
-        if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, true, 0>), dim3((unsigned)tiles), dim3(256), 0, st, a);       \
+        const bool k2 = !a.nred && BM_ == 64 && tiles < 512 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64));                      \
+        if (k2 && lin) hipLaunchKernelGGL((igemm_nt_glds_k2_kernel<BM_, BN_, 3, 1>), dim3((unsigned)tiles), dim3(512), 0, st, a);        \
+        else if (k2) hipLaunchKernelGGL((igemm_nt_glds_k2_kernel<BM_, BN_, 3, 2>), dim3((unsigned)tiles), dim3(512), 0, st, a);          \
+        else if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, true, 0>), dim3((unsigned)tiles), dim3(256), 0, st, a);  \
         else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, 1>), dim3((unsigned)tiles), dim3(256), 0, st, a);    \
         else if (conv1) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, 2>), dim3((unsigned)tiles), dim3(256), 0, st, a);  \
         else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, 0>), dim3((unsigned)tiles), dim3(256), 0, st, a);             \

@@ -63,7 +63,8 @@ def check(got, want, dtype, scale=None, name=''):
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(64, 64, 32), (200, 72, 40), (130, 136, 104), (1216, 1000, 64), (37, 8, 16), (300, 260, 512),
                                    (64, 2048, 512), (64, 512, 2048), (37, 50, 256), (4, 136, 384),
-                                   (24600, 260, 520), (49152, 136, 512)])     # the last two run the LDS-DMA pipeline kernel (bf16)
+                                   (24600, 260, 520), (49152, 136, 512),      # these two run the big LDS-DMA pipeline tiles (bf16)
+                                   (300, 260, 2048), (700, 40, 1088), (3136, 512, 1024)])   # two k-groups per workgroup (bf16)
 def test_gemm_nt_epilogues(dtype, M, N, K):
     _lib, tdt, code = _env()
     rng = np.random.RandomState(M + N + K)
@@ -108,7 +109,7 @@ def _nhwc(x):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-@pytest.mark.parametrize('B,C,H,W,Co,k,s,pad', [(2, 16, 9, 9, 24, 3, 1, 1), (3, 8, 12, 10, 40, 3, 2, 1), (2, 32, 8, 8, 16, 1, 1, 0),
+@pytest.mark.parametrize('B,C,H,W,Co,k,s,pad', [(2, 16, 9, 9, 24, 3, 1, 1), (3, 8, 12, 10, 40, 3, 2, 1), (2, 32, 8, 8, 16, 1, 1, 0), (4, 128, 13, 11, 72, 3, 1, 1),
                                                 (2, 16, 8, 8, 32, 1, 2, 0), (1, 64, 14, 14, 64, 3, 1, 1),
                                                 (48, 64, 33, 31, 136, 3, 1, 1), (64, 64, 57, 57, 128, 3, 2, 1)])   # LDS-DMA pipeline kernel (bf16)
 def test_conv_fwd_dgrad_wgrad(dtype, B, C, H, W, Co, k, s, pad):
