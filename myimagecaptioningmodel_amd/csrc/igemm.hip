@@ -653,7 +653,7 @@ __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// KG = 2: eight waves, two k-groups -- group g takes the k-steps s with s % 2 == g (its own half of every ring slot)
+// KG = 2 / 4: 8 / 16 waves in KG k-groups -- group g takes the k-steps s with s % KG == g (its own part of every ring slot)
 // and the groups' accumulators meet in LDS before the epilogue.  Same tile, same bytes, twice the waves: for
 // deep-K layers whose grid is below ~2 workgroups per CU the loop is bound by per-wave latency, not by MFMA.
 template <int BM, int BN, int NST, bool RED, int LIN, int KG = 1>
@@ -786,23 +786,25 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // retire the (zero-page) tail stages before LDS reuse
     __syncthreads();
-    if constexpr (KG == 2) {            // group 1 hands its accumulators over and leaves; group 0 runs the epilogue
+    if constexpr (KG > 1) {             // groups 1.. hand their accumulators over and leave; group 0 runs the epilogue
         f32x4* xch = reinterpret_cast<f32x4*>(smem);
-        if (grp == 1) {
+        if (grp > 0) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) xch[(i * TN + j) * 256 + tid] = acc[i][j];
+                for (int j = 0; j < TN; ++j) xch[((grp - 1) * TM * TN + i * TN + j) * 256 + tid] = acc[i][j];
         }
         __syncthreads();
-        if (grp == 1) {                 // keep the barrier count of the epilogue's statistics path (two), then leave
+        if (grp > 0) {                  // keep the barrier count of the epilogue's statistics path (two), then leave
             if (a.stats) { __syncthreads(); __syncthreads(); }
             return;
         }
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int g = 0; g < KG - 1; ++g)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += xch[(i * TN + j) * 256 + tid];
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += xch[(g * TM * TN + i * TN + j) * 256 + tid];
     }
     nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
 }
@@ -812,9 +814,9 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
     nt_glds_body<BM, BN, NST, RED, LIN>(a, blockIdx.x, gridDim.x);
 }
 
-template <int BM, int BN, int NST, int LIN>
-__global__ __launch_bounds__(512, 2) void igemm_nt_glds_k2_kernel(IGemmArgs a) {
-    nt_glds_body<BM, BN, NST, false, LIN, 2>(a, blockIdx.x, gridDim.x);
+template <int BM, int BN, int NST, int LIN, int KG>
+__global__ __launch_bounds__(256 * KG, KG == 2 ? 2 : 1) void igemm_nt_glds_kg_kernel(IGemmArgs a) {
+    nt_glds_body<BM, BN, NST, false, LIN, KG>(a, blockIdx.x, gridDim.x);
 }
 
 // Several independent problems (the parity classes of a strided data gradient) in ONE launch: the
@@ -1235,6 +1237,32 @@ static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const
     return 0;
 }
 
+template <int BM, int BN>
+static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
+    const int64_t tiles = (int64_t)cdiv(a.M, BM) * cdiv(a.N, BN);
+    CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
+    const dim3 grid((unsigned)tiles);
+    if constexpr (BM == 64) {
+        // deep K on an under-filled grid: 2 or 4 k-groups per workgroup (more waves, same tile)
+        const bool k2 = !a.nred && tiles < 512 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64));
+        const bool k4 = k2 && tiles <= 256 && a.K >= 2048 && (lin || g->Cin >= 128);
+        if (k2) {
+            if (k4 && lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 4>), grid, dim3(1024), 0, st, a);
+            else if (k4) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 4>), grid, dim3(1024), 0, st, a);
+            else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2>), grid, dim3(512), 0, st, a);
+            CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds, k-groups)");
+            return 0;
+        }
+    }
+    if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, true, 0>), grid, dim3(256), 0, st, a);
+    else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 1>), grid, dim3(256), 0, st, a);
+    else if (conv1) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 0>), grid, dim3(256), 0, st, a);
+    CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
+    return 0;
+}
+
 static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, float* stats, int nred, int dtype, hipStream_t st) {
     if (nt_uses_skinny(g, a.M, a.K, stats != nullptr, dtype)) {
         CAPMI_CHECK(nred == 0, "capmi_igemm_nt_bnred: not available for M <= 64 plain products (see capmi_igemm_nt_bnred_part_rows)");
@@ -1248,24 +1276,9 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
     if (dtype == CAPMI_BF16) {
         const bool lin = g->kh == 1 && g->kw == 1 && g->up == 1 && g->pad == 0 && (g->Ho - 1) * g->sd < g->Hi && (g->Wo - 1) * g->sd < g->Wi;
         const bool conv1 = !lin && g->up == 1 && g->Cin >= 32;
-#define CAPMI_GLDS(BM_, BN_)                                                                                                  \
-    do {                                                                                                                      \
-        const int64_t tiles = (int64_t)cdiv(a.M, BM_) * cdiv(a.N, BN_);                                                       \
-        CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");                                                   \
-        const bool k2 = !a.nred && BM_ == 64 && tiles < 512 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64));                      \
-        if (k2 && lin) hipLaunchKernelGGL((igemm_nt_glds_k2_kernel<BM_, BN_, 3, 1>), dim3((unsigned)tiles), dim3(512), 0, st, a);        \
-        else if (k2) hipLaunchKernelGGL((igemm_nt_glds_k2_kernel<BM_, BN_, 3, 2>), dim3((unsigned)tiles), dim3(512), 0, st, a);          \
-        else if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, true, 0>), dim3((unsigned)tiles), dim3(256), 0, st, a);  \
-        else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, 1>), dim3((unsigned)tiles), dim3(256), 0, st, a);    \
-        else if (conv1) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, 2>), dim3((unsigned)tiles), dim3(256), 0, st, a);  \
-        else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM_, BN_, 3, false, 0>), dim3((unsigned)tiles), dim3(256), 0, st, a);             \
-        CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");                                                                           \
-        return 0;                                                                                                             \
-    } while (0)
-        if (c.wmw == 5) CAPMI_GLDS(64, 64);         // 64x64 LDS-DMA tiles
-        if (c.bn == 128 && c.bm == 128) CAPMI_GLDS(128, 128);
-        if (c.bn == 128) CAPMI_GLDS(64, 128);
-#undef CAPMI_GLDS
+        if (c.wmw == 5) return launch_glds<64, 64>(a, g, lin, conv1, st);           // 64x64 LDS-DMA tiles
+        if (c.bn == 128 && c.bm == 128) return launch_glds<128, 128>(a, g, lin, conv1, st);
+        if (c.bn == 128) return launch_glds<64, 128>(a, g, lin, conv1, st);
         if (c.bm == 128 && c.bn == 64) return launch_nt<bf16, 128, 64, 4>(a, st);
         return launch_nt<bf16, 64, 64, 4>(a, st);
     } else if (dtype == CAPMI_F32) {
