@@ -154,7 +154,7 @@ int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, 
  *   bn_stats   : ws[part][C][2] = exact (mean, sum (x-mean)^2) of every block of
  *                capmi_bn_stats_part_rows(M,C,dtype) rows (two passes over the block, no atomics)
  *   bn_finalize: merges the parts (Chan's formula, f64; two levels when there are many -- ws must
- *                have room for 32 extra parts: [ceil(M/part_rows) + 32][C][2]) into mean / biased
+ *                have room for 64 extra parts: [ceil(M/part_rows) + 64][C][2]) into mean / biased
  *                variance over M rows;
  *                writes saved_mean, saved_invstd, coef_a = scale*invstd, and updates the running
  *                stats with momentum (run = m*run + (1-m)*batch)

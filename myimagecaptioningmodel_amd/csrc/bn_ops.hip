@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-#define CAPMI_BN_MERGE_GROUPS 32     // ws must have room for this many extra parts (capmi.h)
+#define CAPMI_BN_MERGE_GROUPS 32     // merged groups (64 for C <= 128: few channel blocks, so more row groups); ws has room for 64 extra parts (capmi.h)
 
 extern "C" int capmi_bn_finalize(float* ws, int part_rows, int M, int C, const float* scale, float* run_mean, float* run_var,
                                  float momentum, float eps, float* saved_mean, float* saved_invstd, float* coef_a,
@@ -154,7 +154,7 @@ extern "C" int capmi_bn_finalize(float* ws, int part_rows, int M, int C, const f
     const float* src = ws;
     int rows = part_rows;
     if (nparts > 2 * CAPMI_BN_MERGE_GROUPS) {
-        const int k = cdiv(nparts, CAPMI_BN_MERGE_GROUPS);
+        const int k = cdiv(nparts, C <= 128 ? 2 * CAPMI_BN_MERGE_GROUPS : CAPMI_BN_MERGE_GROUPS);
         float* merged = ws + (int64_t)nparts * C * 2;
         hipLaunchKernelGGL(bn_merge_kernel, dim3(cdiv(C, 64), cdiv(nparts, k)), dim3(256), 0, (hipStream_t)stream, ws, part_rows, M, C, k, merged);
         src = merged;
@@ -270,7 +270,7 @@ extern "C" int capmi_bn_finalize_apply(float* ws, int part_rows, int M, int C, c
     const float* src = ws;
     int rows = part_rows;
     if (nparts > 2 * CAPMI_BN_MERGE_GROUPS) {
-        const int k = cdiv(nparts, CAPMI_BN_MERGE_GROUPS);
+        const int k = cdiv(nparts, C <= 128 ? 2 * CAPMI_BN_MERGE_GROUPS : CAPMI_BN_MERGE_GROUPS);
         float* merged = ws + (int64_t)nparts * C * 2;
         hipLaunchKernelGGL(bn_merge_kernel, dim3(cdiv(C, 64), cdiv(nparts, k)), dim3(256), 0, (hipStream_t)stream, ws, part_rows, M, C, k, merged);
         src = merged;

@@ -125,7 +125,7 @@ class EncoderRunner:
                     kk = self.kpad_of(op) if op.src == 0 else op.k * op.k * op.cin
                     part_rows = lib().capmi_igemm_nt_stats_part_rows(M, c, kk, dtype_code)
                 nparts = (M + part_rows - 1) // part_rows
-                self.bn[op.dst] = dict(stats=z((nparts + 32, c, 2), torch.float32), part_rows=part_rows, mean=z((c,), torch.float32),
+                self.bn[op.dst] = dict(stats=z((nparts + 64, c, 2), torch.float32), part_rows=part_rows, mean=z((c,), torch.float32),
                                        invstd=z((c,), torch.float32), a=z((c,), torch.float32))
                 max_elems = max(max_elems, B * h * w * c)
             elif isinstance(op, arch.MaxPool):

@@ -381,7 +381,7 @@ def test_batch_norm_chain(dtype, act, res):
     f32 = torch.float32
     X = dev(_nhwc(x), tdt[dtype])
     pr = _lib.lib().capmi_bn_stats_part_rows(M, C, code[dtype])
-    stats = torch.full((((M + pr - 1) // pr + 32) * C * 2,), float('nan'), dtype=f32, device=DEV)
+    stats = torch.full((((M + pr - 1) // pr + 64) * C * 2,), float('nan'), dtype=f32, device=DEV)
     _lib.call('capmi_bn_stats', p(X), M, C, p(stats), code[dtype], stream())
     SC, OF, RM, RV = dev(scale, f32), dev(offset, f32), dev(rm, f32), dev(rv, f32)
     mean, invstd, ca = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(3))
@@ -430,7 +430,7 @@ def test_batch_norm_statistics_no_cancellation():
     X = dev(x, torch.float32)
     f32 = torch.float32
     pr = _lib.lib().capmi_bn_stats_part_rows(M, C, _lib.F32)
-    ws = torch.zeros((((M + pr - 1) // pr + 32) * C * 2,), dtype=f32, device=DEV)
+    ws = torch.zeros((((M + pr - 1) // pr + 64) * C * 2,), dtype=f32, device=DEV)
     _lib.call('capmi_bn_stats', p(X), M, C, p(ws), _lib.F32, stream())
     ones, zeros = torch.ones(C, dtype=f32, device=DEV), torch.zeros(C, dtype=f32, device=DEV)
     mean, invstd, ca = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(3))
@@ -446,7 +446,7 @@ def test_batch_norm_statistics_no_cancellation():
     eye = torch.eye(C, dtype=f32, device=DEV)
     Y = torch.zeros((M, C), dtype=f32, device=DEV)
     pr2 = _lib.lib().capmi_igemm_nt_stats_part_rows(M, C, C, _lib.F32)
-    ws2 = torch.zeros((((M + pr2 - 1) // pr2 + 32) * C * 2,), dtype=f32, device=DEV)
+    ws2 = torch.zeros((((M + pr2 - 1) // pr2 + 64) * C * 2,), dtype=f32, device=DEV)
     _lib.call('capmi_igemm_nt', p(X), p(eye), p(Y), _lib.gemm_geom(M, C), C, C, C, None, None, 0, None, 0, p(ws2), 0, 0, 0, _lib.F32, stream())
     _lib.call('capmi_bn_finalize', p(ws2), pr2, M, C, p(ones), None, None, 0.9, 1e-5, p(mean), p(invstd), p(ca), 0, stream())
     np.testing.assert_allclose(host(invstd), 1 / np.sqrt(x64.var(0) + 1e-5), rtol=1e-4)
