@@ -184,6 +184,7 @@ class CaptionEngine:
     def _compile_eval(self, B):
         cfg, S = self.cfg, self.cfg['image_size']
         enc = EncoderRunner(self.store, B, S, self.code, self.tdt, False)
+        enc.overlap_forward = False         # one lane: the whole decode (encoder + Ti sequential steps) replays from a hipGraph
         K = enc.shape[enc.out_id][0] * enc.shape[enc.out_id][1]
         Ti = cfg['infer_max_length']
         dec = DecoderRunner(self.store, B, K, 1, self.code, self.tdt, self.slots, False)
