@@ -241,34 +241,31 @@ class Plan:
             side = Plan._side[dev] = (s, e0, e1)
         s1, fork_ev, join_ev = side
         prog = getattr(self, '_prog', None)
-        if prog is None or self._prog_len != len(self.calls):
-            # compiled form: (kind, a, b, lane); waits on keys recorded in an earlier run are dropped
+        if prog is None or self._prog_key != (len(self.calls), stream, s1.value):
+            # compiled form: ('launch', raw entry point, args + stream) / ('record' | 'wait', event, stream); waits on
+            # keys recorded in an earlier run are dropped; stream pointers are baked in (the key checks them)
             prog, events = [], {}
+            ptrs = (stream, s1)
             for fn, name, args in self.calls:
                 if fn is None:
                     key, lane = args
                     if name == 'record':
                         ev = ctypes.c_void_p()
-                        if lib().capmi_event_create(ctypes.byref(ev)) != 0:
+                        if L.capmi_event_create(ctypes.byref(ev)) != 0:
                             raise CapmiError('capmi_event_create: %s' % last_error())
                         events[key] = ev
-                        prog.append((1, ev, None, lane))
+                        prog.append((1, L.capmi_event_record, (ev, ptrs[lane])))
                     elif key in events:
-                        prog.append((2, events[key], None, lane))
+                        prog.append((2, L.capmi_stream_wait_event, (ptrs[lane], events[key])))
                 else:
-                    prog.append((0, fn, args, getattr(fn, 'lane', 0)))
-            self._prog, self._prog_len = prog, len(self.calls)
-        ptrs = (stream, s1)
+                    lane = getattr(fn, 'lane', 0)
+                    prog.append((0, getattr(fn, 'fn', fn), tuple(args) + (ptrs[lane],)))
+            self._prog, self._prog_key = prog, (len(self.calls), stream, s1.value)
         L.capmi_event_record(fork_ev, stream)             # fork
         L.capmi_stream_wait_event(s1, fork_ev)
-        for kind, a, b, lane in prog:
-            if kind == 0:
-                if a(*b, ptrs[lane]) != 0:
-                    raise CapmiError('launch failed: %s' % last_error())
-            elif kind == 1:
-                L.capmi_event_record(a, ptrs[lane])
-            else:
-                L.capmi_stream_wait_event(ptrs[lane], a)
+        for kind, fn, args in prog:
+            if fn(*args) != 0:
+                raise CapmiError('launch failed: %s' % last_error())
         L.capmi_event_record(join_ev, s1)                 # join
         L.capmi_stream_wait_event(stream, join_ev)
 
