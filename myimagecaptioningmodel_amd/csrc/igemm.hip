@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
 }
 
 template <int BM, int BN, int NST, int LIN, int KG>
-__global__ __launch_bounds__(256 * KG, KG == 2 ? 2 : 1) void igemm_nt_glds_kg_kernel(IGemmArgs a) {
+__global__ __launch_bounds__(256 * KG, (KG == 2 && BM == 64) ? 2 : 1) void igemm_nt_glds_kg_kernel(IGemmArgs a) {
     nt_glds_body<BM, BN, NST, false, LIN, KG>(a, blockIdx.x, gridDim.x);
 }
 
@@ -1172,6 +1172,8 @@ static NtCfg nt_cfg(int M, int N, int K, int dtype) {
     if (dtype == CAPMI_BF16) {
         if (wide) {
             const bool big = K >= 512 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 384;   // LDS-DMA pipeline kernel: deep K, full grid
+            const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128);
+            if (!big && K >= 1024 && t128 >= 160 && t128 <= 256) return NtCfg{128, 128, 4};      // one round of 128x128 tiles, two k-groups each
             if (!big && (int64_t)cdiv(M, 64) * cdiv(N, 128) < 256) return NtCfg{64, 64, 5};      // under-filled grid: 64x64 LDS-DMA tiles (wmw 5 = marker)
             return NtCfg{big ? 128 : 64, 128, 4};
         }
@@ -1242,6 +1244,14 @@ static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, b
     const int64_t tiles = (int64_t)cdiv(a.M, BM) * cdiv(a.N, BN);
     CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
     const dim3 grid((unsigned)tiles);
+    if constexpr (BM == 128) {
+        if (!a.nred && tiles <= 256 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64))) {
+            if (lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2>), grid, dim3(512), 0, st, a);
+            CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds 128, k-groups)");
+            return 0;
+        }
+    }
     if constexpr (BM == 64) {
         // deep K on an under-filled grid: 2 or 4 k-groups per workgroup (more waves, same tile)
         const bool k2 = !a.nred && tiles < 512 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64));

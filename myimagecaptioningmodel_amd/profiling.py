@@ -31,6 +31,8 @@ def _nt_tile(M, N, K, bf16):
     if bf16:
         if wide:
             big = K >= 512 and cd(M, 128) * cd(N, 128) >= 384
+            if not big and K >= 1024 and 160 <= cd(M, 128) * cd(N, 128) <= 256:
+                return (128, 128, True)
             if not big and cd(M, 64) * cd(N, 128) < 256:
                 return (64, 64, True)
             return (128 if big else 64, 128, True)
