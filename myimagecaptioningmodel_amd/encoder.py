@@ -7,8 +7,11 @@ Forward of one `conv -> batch_norm -> relu6` unit (the reference's `conv_bn_laye
     -> bn_apply (normalise + activation, with the shortcut add of :123-124 folded in).
 Activations are NHWC in HBM, so the encoder output [B, S/32, S/32, C] already IS the
 [B, K, C] matrix `_img2feature` builds with reshape+transpose
-(model_adaAttention_aic.py:193-195).  Backward mirrors it: bn_bwd_reduce -> bn_bwd_apply ->
-weight-gradient GEMM (split over pixels, f32 atomics) -> data-gradient GEMM.
+(model_adaAttention_aic.py:193-195).  Backward mirrors it on two lanes (HIP streams): the main lane runs
+bn_bwd_reduce -> bn_bwd_apply -> data-gradient GEMM (which applies the ReLU mask of the tensor whose gradient it
+completes); the weight-gradient GEMM of the layer, and the whole backward of a projection shortcut, run on the side
+lane between device-scope events.  The stem reads a 2x2 space-to-depth copy of the feed (capmi_s2d_stem) and is an
+ordinary stride-1 implicit GEMM; strided data gradients are one dense GEMM per output-parity class.
 """
 import os
 

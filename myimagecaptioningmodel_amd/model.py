@@ -9,8 +9,9 @@ Feeds: `image` float32 [B,3,S,S] (NCHW), `caption` int64 [B,L].  Fetches: loss f
 lr float32 [1]; eval `caption` ids float32 [B,Ti] (quirk Q2).  Errors: ValueError on a bad
 mode, AssertionError on NaN loss (train.py:140-141) are raised by the callers in train_loop.py.
 
-All arithmetic runs in libcapmi.so (hand-written gfx950 kernels) through static launch plans;
-torch only owns device memory, streams, hipGraph capture and torch.distributed.
+All arithmetic runs in libcapmi.so (hand-written gfx950 kernels) through static launch plans: the train
+step is launched on two HIP streams (main chain + side lane, _lib.Plan), the decode plan replays from a
+hipGraph; torch only owns device memory, the current stream, graph capture and torch.distributed.
 """
 import os
 
