@@ -1579,31 +1579,32 @@ __global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
     // branch-free addressing (selects only): the loop is bound by instruction issue, not by memory
     const int tap_h = kp.r - a.g.pad, tap_w = kp.q - a.g.pad;       // input row = ho*sd + tap_h
     const int sd = a.g.sd, Hi = a.g.Hi, Wi = a.g.Wi, ldx = a.g.ldx, ldy = a.ldy;
+    // Source addresses as integers, invalid lanes folded onto the zero page by a mask (delta & -ok): pure arithmetic,
+    // the compiler cannot turn it back into exec-masked branches around the address computation.
+    const uint64_t zaddr = (uint64_t)zero, yaddr0 = (uint64_t)(DY + ncol), xaddr0 = (uint64_t)X;
     auto issue_stage = [&](int st, int mt) {
         char* base = smem + st * STB + wave * 1024;
-        constexpr int j = 0;
-        {
-            const int m = mt + r0;
-            const bool ok = m < m_end;
-            const T* ysrc = DY + (int64_t)m * ldy + ncol;
-            ysrc = (ok && yok) ? ysrc : zero;
-            const T* xsrc;
-            if (a.linear) {         // 1x1 / stride 1: A(m, k) = x[m][k]
-                xsrc = X + ((int64_t)m * ldx + kp.k);
-                xsrc = (ok && xok) ? xsrc : zero;
-            } else {
-                const int b = fdiv(m, a.fd_hw), rem = m - b * a.fd_hw.d;
-                const int ho = fdiv(rem, a.fd_w), wo = rem - ho * a.fd_w.d;
-                const int hn = ho * sd + tap_h, wn = wo * sd + tap_w;
-                const bool okx = ok && xok && (unsigned)hn < (unsigned)Hi && (unsigned)wn < (unsigned)Wi;
-                xsrc = X + ((int64_t)((b * Hi + hn) * Wi + wn) * ldx + kp.c);
-                xsrc = okx ? xsrc : zero;
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ysrc,
-                                             (__attribute__((address_space(3))) void*)(base + j * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
-                                             (__attribute__((address_space(3))) void*)(base + OPB + j * 1024), 16, 0, 0);
+        const int m = mt + r0;
+        const int64_t ok = m < m_end ? -1 : 0;
+        const uint64_t ya = yaddr0 + (uint64_t)((int64_t)m * ldy) * 2;
+        const uint64_t ysrc = zaddr + ((ya - zaddr) & (uint64_t)(yok ? ok : 0));
+        uint64_t xa;
+        int64_t okx;
+        if (a.linear) {             // 1x1 / stride 1: A(m, k) = x[m][k]
+            xa = xaddr0 + (uint64_t)((int64_t)m * ldx + kp.k) * 2;
+            okx = xok ? ok : 0;
+        } else {
+            const int b = fdiv(m, a.fd_hw), rem = m - b * a.fd_hw.d;
+            const int ho = fdiv(rem, a.fd_w), wo = rem - ho * a.fd_w.d;
+            const int hn = ho * sd + tap_h, wn = wo * sd + tap_w;
+            okx = (xok && (unsigned)hn < (unsigned)Hi && (unsigned)wn < (unsigned)Wi) ? ok : 0;
+            xa = xaddr0 + (uint64_t)((int64_t)((b * Hi + hn) * Wi + wn) * ldx + kp.c) * 2;
         }
+        const uint64_t xsrc = zaddr + ((xa - zaddr) & (uint64_t)okx);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ysrc,
+                                         (__attribute__((address_space(3))) void*)base, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
+                                         (__attribute__((address_space(3))) void*)(base + OPB), 16, 0, 0);
     };
 
     f32x4 acc[TN_][TK_];
