@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
     // 8 waves: 2 (n) x 4 (k), each a 64 x 32 sub-tile -- the loop is bound by per-wave instruction issue
     // and LDS/MFMA latency, so the same tile and LDS footprint is shared by twice the waves
     typedef bf16 T;
-    constexpr int BNO = 128, BKO = 128, RM = 32, NST = 3;
+    constexpr int BNO = 128, BKO = 128, RM = 64, NST = 3;     // 64 reduction rows per stage: two MFMA k-steps per barrier
     constexpr int OPB = RM * 256, STB = 2 * OPB;            // bytes per operand tile / per stage
     constexpr int TN_ = 4, TK_ = 2;
     __shared__ __attribute__((aligned(1024))) char smem[NST * STB];
@@ -1583,8 +1583,10 @@ __global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
     // the compiler cannot turn it back into exec-masked branches around the address computation.
     const uint64_t zaddr = (uint64_t)zero, yaddr0 = (uint64_t)(DY + ncol), xaddr0 = (uint64_t)X;
     auto issue_stage = [&](int st, int mt) {
-        char* base = smem + st * STB + wave * 1024;
-        const int m = mt + r0;
+#pragma unroll
+      for (int h = 0; h < RM / 32; ++h) {       // rows r0 and r0 + 32: the same chunk swizzle f(row)
+        char* base = smem + st * STB + h * 8192 + wave * 1024;
+        const int m = mt + r0 + 32 * h;
         const int64_t ok = m < m_end ? -1 : 0;
         const uint64_t ya = yaddr0 + (uint64_t)((int64_t)m * ldy) * 2;
         const uint64_t ysrc = zaddr + ((ya - zaddr) & (uint64_t)(yok ? ok : 0));
@@ -1605,6 +1607,7 @@ __global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
                                          (__attribute__((address_space(3))) void*)base, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)xsrc,
                                          (__attribute__((address_space(3))) void*)(base + OPB), 16, 0, 0);
+      }
     };
 
     f32x4 acc[TN_][TK_];
@@ -1620,21 +1623,24 @@ __global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
     for (int p = 0; p < NST - 1; ++p) issue_stage(p, rows_of(p));
     int slot = 0;
     for (int s = 0; s < nsteps; ++s) {
-        wait_vmcnt<(NST - 2) * 2>();                          // this thread's part of stage s has landed
+        wait_vmcnt<(NST - 2) * 2 * (RM / 32)>();              // this thread's part of stage s has landed
         __builtin_amdgcn_s_barrier();                         // ... everyone's; all waves are done with stage s-1
         asm volatile("" ::: "memory");
         issue_stage(slot == 0 ? NST - 1 : slot - 1, rows_of(s + NST - 1));
         const char* st = smem + slot * STB;
         slot = slot + 1 == NST ? 0 : slot + 1;
-        Frag<T> af[TN_], bf[TK_];
 #pragma unroll
-        for (int i = 0; i < TN_; ++i) load_frag_tr_swz(af[i], st, fg, wn * 64 + i * 16, fr);
+        for (int ks = 0; ks < RM / 32; ++ks) {
+            Frag<T> af[TN_], bf[TK_];
 #pragma unroll
-        for (int j = 0; j < TK_; ++j) load_frag_tr_swz(bf[j], st + OPB, fg, wk * 32 + j * 16, fr);
+            for (int i = 0; i < TN_; ++i) load_frag_tr_swz(af[i], st + ks * 8192, fg, wn * 64 + i * 16, fr);
 #pragma unroll
-        for (int i = 0; i < TN_; ++i)
+            for (int j = 0; j < TK_; ++j) load_frag_tr_swz(bf[j], st + OPB + ks * 8192, fg, wk * 32 + j * 16, fr);
 #pragma unroll
-            for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[i], bf[j]);
+            for (int i = 0; i < TN_; ++i)
+#pragma unroll
+                for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[i], bf[j]);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tn_epilogue<BNO, BKO, TN_, TK_>(a, acc, n0, k0, split, wn, wk, fr, fg);
