@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
     // 8 waves: 2 (n) x 4 (k), each a 64 x 32 sub-tile -- the loop is bound by per-wave instruction issue
     // and LDS/MFMA latency, so the same tile and LDS footprint is shared by twice the waves
     typedef bf16 T;
-    constexpr int BNO = 128, BKO = 128, RM = 64, NST = 3;     // 64 reduction rows per stage: two MFMA k-steps per barrier
+    constexpr int BNO = 128, BKO = 128, RM = 64, NST = 2;     // 64 reduction rows per stage: two MFMA k-steps per barrier
     constexpr int OPB = RM * 256, STB = 2 * OPB;            // bytes per operand tile / per stage
     constexpr int TN_ = 4, TK_ = 2;
     __shared__ __attribute__((aligned(1024))) char smem[NST * STB];
@@ -1629,18 +1629,21 @@ __global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
         issue_stage(slot == 0 ? NST - 1 : slot - 1, rows_of(s + NST - 1));
         const char* st = smem + slot * STB;
         slot = slot + 1 == NST ? 0 : slot + 1;
+        Frag<T> af[RM / 32][TN_], bf[RM / 32][TK_];
 #pragma unroll
         for (int ks = 0; ks < RM / 32; ++ks) {
-            Frag<T> af[TN_], bf[TK_];
 #pragma unroll
-            for (int i = 0; i < TN_; ++i) load_frag_tr_swz(af[i], st + ks * 8192, fg, wn * 64 + i * 16, fr);
+            for (int i = 0; i < TN_; ++i) load_frag_tr_swz(af[ks][i], st + ks * 8192, fg, wn * 64 + i * 16, fr);
 #pragma unroll
-            for (int j = 0; j < TK_; ++j) load_frag_tr_swz(bf[j], st + OPB + ks * 8192, fg, wk * 32 + j * 16, fr);
+            for (int j = 0; j < TK_; ++j) load_frag_tr_swz(bf[ks][j], st + OPB + ks * 8192, fg, wk * 32 + j * 16, fr);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // every transposing read of the stage in flight before the first MFMA
+#pragma unroll
+        for (int ks = 0; ks < RM / 32; ++ks)
 #pragma unroll
             for (int i = 0; i < TN_; ++i)
 #pragma unroll
-                for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[i], bf[j]);
-        }
+                for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[ks][i], bf[ks][j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tn_epilogue<BNO, BKO, TN_, TK_>(a, acc, n0, k0, split, wn, wk, fr, fg);
