@@ -279,3 +279,57 @@ def test_train_step_with_fused_lstm_steps(dtype, monkeypatch):
         num = np.sqrt(sum(np.sum((ge[k] - go[k]) ** 2) for k in go))
         den = np.sqrt(sum(np.sum(go[k] ** 2) for k in go))
         assert num <= 2e-3 * den, num / den
+
+
+def test_baseline_config0_repo_default_model():
+    """BASELINE.json configs[0], the reference's own CPU-runnable case: repo-default encoder + decoder (MobileNetV2,
+    hidden 1024, embed 256, singleton attention, f32) on 64x64 images, vocab 1000, seq_len 10, batch 4 -- loss
+    within 1e-3 of the oracle, gradients in relative L2, greedy ids bit-exact (north_star tolerances)."""
+    ocfg = om.default_cfg(encoder='mobilenetv2', image_size=64, hidden=1024, embed=256, vocab=1000, sentence_length=10,
+                          infer_max_length=10, attention='singleton')
+    from myimagecaptioningmodel_amd import default_cfg
+    ecfg = default_cfg(encoder='mobilenetv2', image_size=64, hidden=1024, embed=256, vocab=1000, sentence_length=10,
+                       infer_max_length=10, attention='singleton', dtype='f32', learning_rate=1e-4, batch_size=4)
+    params, image, caption = _data(ocfg, 4, 7)
+    o = om.OracleModel(ocfg, params)
+    lo, _ = o.forward_train(image.astype(np.float64), caption, update_stats=False)
+    go = o.backward()
+    eng = _engine(ecfg, params)
+    le = float(eng.forward_backward(image, caption).cpu()[0])
+    assert abs(le - lo) <= 1e-3, (le, lo)
+    ge = eng.export_reference_grads()
+    # batch 4 at 64x64 puts 16 samples under the last batch norms: calibrate against the f32 NumPy evaluation of the
+    # same graph (see test_f32_train_step_matches_oracle)
+    _, g32 = _f32_oracle_noise(ocfg, params, image, caption)
+    num = np.sqrt(sum(np.sum((ge[k] - go[k]) ** 2) for k in go))
+    noise = np.sqrt(sum(np.sum((g32[k].astype(np.float64) - go[k]) ** 2) for k in go))
+    den = np.sqrt(sum(np.sum(go[k] ** 2) for k in go))
+    print('config[0] gradient relative-L2 error %.2e (f32 NumPy noise floor %.2e)' % (num / den, noise / den))
+    assert num <= max(5e-3 * den, 10 * noise), (num / den, noise / den)
+    ids_o, logits_o = om.OracleModel(ocfg, {k: v.copy() for k, v in params.items()}).greedy_decode(image.astype(np.float64))
+    eng2 = _engine(ecfg, params)                 # fresh running statistics, as the oracle's
+    ids_e = eng2.decode(image).cpu().numpy()
+    top2 = np.sort(logits_o, axis=-1)[..., -2:]
+    assert (top2[..., 1] - top2[..., 0]).min() > 1e-3, 'test inputs have a near-tie; change the seed'
+    assert ids_e.dtype == np.float32
+    np.testing.assert_array_equal(ids_e, ids_o)
+
+
+def test_resnet101_encoder_small():
+    """The deeper build-defined encoder of BASELINE.json configs[3] (ResNet-101) at a size the oracle finishes in
+    seconds: loss and all gradients against the oracle."""
+    ocfg, ecfg = _cfgs('resnet101', 'slots', 'f32', S=64, H=48, E=24, V=80, L=6)
+    params, image, caption = _data(ocfg, 2, 13)
+    o = om.OracleModel(ocfg, params)
+    lo, _ = o.forward_train(image.astype(np.float64), caption, update_stats=False)
+    go = o.backward()
+    eng = _engine(ecfg, params)
+    le = float(eng.forward_backward(image, caption).cpu()[0])
+    assert abs(le - lo) <= 1e-3, (le, lo)
+    ge = eng.export_reference_grads()
+    _, g32 = _f32_oracle_noise(ocfg, params, image, caption)
+    num = np.sqrt(sum(np.sum((ge[k] - go[k]) ** 2) for k in go))
+    noise = np.sqrt(sum(np.sum((g32[k].astype(np.float64) - go[k]) ** 2) for k in go))
+    den = np.sqrt(sum(np.sum(go[k] ** 2) for k in go))
+    print('resnet101 gradient relative-L2 error %.2e (f32 NumPy noise floor %.2e)' % (num / den, noise / den))
+    assert num <= max(5e-3 * den, 10 * noise), (num / den, noise / den)      # 104 BN layers over 2 x (2 x 2) pixels
