@@ -28,11 +28,14 @@ def init_process_group_from_env(backend=None):
         return None, 0, 1, 0
     rank = int(os.environ['RANK'])
     local = int(os.environ.get('LOCAL_RANK', rank))
+    if torch.cuda.is_available():
+        local %= torch.cuda.device_count()          # rehearsal on a box with fewer GPUs than ranks
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'     # 'nccl' is RCCL on ROCm
-    if backend == 'nccl':
+        # 'nccl' is RCCL on ROCm; CAPMI_DIST_BACKEND=gloo rehearses the N > 1 path where RCCL cannot run (two ranks on one GPU)
+        backend = os.environ.get('CAPMI_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
