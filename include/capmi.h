@@ -173,6 +173,10 @@ int capmi_bn_finalize(float* ws, int part_rows, int M, int C, const float* scale
                       int update_running, void* stream);
 int capmi_bn_apply(const void* x, const float* saved_mean, const float* coef_a, const float* offset,
                    const void* res, void* y, int M, int C, int act, int dtype, void* stream);
+/* Inference mode (fluid batch_norm is_test=True, the exported model of infer.py): mean = running mean,
+ * coef_a = scale / sqrt(running variance + eps); follow with capmi_bn_apply. */
+int capmi_bn_inference_coef(const float* scale, const float* run_mean, const float* run_var, float eps, float* mean,
+                            float* coef_a, int C, void* stream);
 /* capmi_bn_finalize + capmi_bn_apply in ONE launch (plus the merge launch for > 64 parts): every apply workgroup
  * merges the statistic groups of its own channels (f64, Chan) before normalising its rows; saved mean / invstd and
  * the running statistics are written by the first workgroup row.  Same results as the two calls.  Measured
@@ -275,6 +279,20 @@ int capmi_softmax_xent_bwd(const float* logits, const int64_t* target, const flo
                            int padding_idx, int dtype, void* stream);
 /* layers.argmax (:120): lowest index on ties; ids_out int64 [M], also f32 copy (quirk Q2). */
 int capmi_argmax(const float* logits, int64_t* ids_out, float* ids_f32, int ld_f32, int M, int V, int ld, void* stream);
+
+/* Beam-search decode (BUILD-DEFINED extension of the eval graph, BASELINE cfg 5; infer.py only has the greedy loop).
+ * Rows are beam-major: row k*B + b holds hypothesis k of image b.  One step: capmi_beam_step takes the f32 logits
+ * [beam*B][ld] of the current hypotheses and their scores [beam][B] (sum of log-softmax probabilities) and keeps, per
+ * image, the `beam` best of the beam x V continuations (ties: lower beam index, then lower token id): new scores,
+ * parents / tokens [beam][B] of this step, the next input ids and the rows to gather the LSTM state from
+ * (capmi_gather_rows).  cand_val / cand_idx [beam*B][beam] and lse [beam*B] are scratch.  No early stop and no
+ * special casing of <stop> (quirk Q5 carried over): beam = 1 is exactly the greedy loop.  capmi_beam_backtrack walks
+ * the parents [Ti][beam][B] back from the best final hypothesis and writes float32 ids [B][Ti] (quirk Q2). beam <= 8. */
+int capmi_beam_step(const float* logits, int V, int ld, int B, int beam, const float* score_in, float* score_out,
+                    float* cand_val, int* cand_idx, float* lse, int* parents, int* tokens, int64_t* next_ids,
+                    int* gather_rows, void* stream);
+int capmi_gather_rows(const void* src, const int* rows, void* dst, int n, int H, int dtype, void* stream);
+int capmi_beam_backtrack(const int* tokens, const int* parents, float* out_ids_f32, int Ti, int B, int beam, void* stream);
 
 /* fluid.optimizer.Adam, Paddle-1.8 form, over one flat f32 range (IC/train.py:26-31,45) with
  * optional GradientClipByValue (:42-43; clip <= 0 disables):

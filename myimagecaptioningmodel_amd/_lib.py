@@ -54,6 +54,7 @@ SIGNATURES = {
     'capmi_bn_stats': [_p, _i, _i, _p, _i, _p],
     'capmi_bn_finalize': [_p, _i, _i, _i, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p],
     'capmi_bn_apply': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_bn_inference_coef': [_p, _p, _p, _f, _p, _p, _i, _p],
     'capmi_bn_finalize_apply': [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _i, _p, _p, _p, _i, _i, _p],
     'capmi_bn_bwd_reduce': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_reduce_final': [_p, _i, _i, _p, _p],
@@ -70,6 +71,9 @@ SIGNATURES = {
     'capmi_lstm_cell_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_lstm_step_fwd': [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     'capmi_lstm_step_bwd': [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_beam_step': [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'capmi_gather_rows': [_p, _p, _p, _i, _i, _i, _p],
+    'capmi_beam_backtrack': [_p, _p, _p, _i, _i, _i, _p],
     'capmi_sentinel_fwd': [_p, _p, _p, _l, _i, _p],
     'capmi_sentinel_bwd': [_p, _p, _p, _p, _p, _l, _i, _p],
     'capmi_ada_attention_fwd': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],

@@ -288,6 +288,24 @@ extern "C" int capmi_bn_finalize_apply(float* ws, int part_rows, int M, int C, c
     return 0;
 }
 
+// ------------------------------------------------------------------ inference-mode coefficients (is_test)
+// The exported inference model normalises with the RUNNING statistics (fluid batch_norm is_test=True, infer.py /
+// save_inference_model): mean = running mean, a = scale / sqrt(running variance + eps); then capmi_bn_apply.
+__global__ __launch_bounds__(256) void bn_inference_coef_kernel(const float* __restrict__ scale, const float* __restrict__ run_mean,
+                                                                const float* __restrict__ run_var, float eps, float* mean, float* coef_a, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    mean[c] = run_mean[c];
+    coef_a[c] = scale[c] / sqrtf(run_var[c] + eps);
+}
+extern "C" int capmi_bn_inference_coef(const float* scale, const float* run_mean, const float* run_var, float eps, float* mean,
+                                       float* coef_a, int C, void* stream) {
+    CAPMI_CHECK(scale && run_mean && run_var && mean && coef_a, "capmi_bn_inference_coef: null pointer");
+    hipLaunchKernelGGL(bn_inference_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, scale, run_mean, run_var, eps, mean, coef_a, C);
+    CAPMI_LAUNCH_CHECK("capmi_bn_inference_coef");
+    return 0;
+}
+
 // ------------------------------------------------------------------ apply: y = act(a*(x - mean) + offset (+ res))
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ ca,

@@ -694,6 +694,136 @@ extern "C" int capmi_argmax(const float* logits, int64_t* ids_out, float* ids_f3
     return 0;
 }
 
+// ------------------------------------------------------------------ beam search (build-defined extension of the decode path)
+// Semantics = oracle/model.py beam_decode: rows are beam-major (row k*B + b), score = sum of log-softmax
+// probabilities, ties to the lower beam index then the lower token id, no special casing of <stop>.
+// Step 1 (one workgroup per row): log-sum-exp of the row and its `beam` largest logits (value desc, index asc).
+__global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict__ logits, int V, int ld, int beam, float* cand_val,
+                                                        int* cand_idx, float* lse) {
+    __shared__ float scratch[16];
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ int chosen[8];
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (int64_t)m * ld;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) mx = fmaxf(mx, row[i]);
+    mx = block_max(mx, scratch);
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 256) sum += expf(row[i] - mx);
+    sum = block_sum(sum, scratch);
+    if (tid == 0) lse[m] = mx + logf(sum);
+    for (int r = 0; r < beam; ++r) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid; i < V; i += 256) {
+            bool taken = false;
+            for (int q = 0; q < r; ++q) taken |= chosen[q] == i;
+            const float f = row[i];
+            if (!taken && (f > best || (f == best && i < bi))) { best = f; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ob = __shfl_xor(best, o, 64);
+            int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+            if (bi == 0x7fffffff) { bi = 0; best = -INFINITY; }      // V < beam: fewer candidates than ranks
+            chosen[r] = bi;
+            cand_val[(int64_t)m * beam + r] = best;
+            cand_idx[(int64_t)m * beam + r] = bi;
+        }
+        __syncthreads();
+    }
+}
+// Step 2 (one thread per image): the `beam` best of the beam x beam candidates by score[k] + logit - lse[k];
+// writes the new scores, (parent, token) of step t, the next input ids and the state-gather rows.
+__global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                         const float* __restrict__ lse, const float* __restrict__ score_in, int B, int beam,
+                                                         float* score_out, int* parents, int* tokens, int64_t* next_ids, int* gather_rows) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    unsigned long long used = 0;           // candidate (k, r) -> bit k*beam + r   (beam <= 8)
+    for (int j = 0; j < beam; ++j) {
+        float best = -INFINITY;
+        int bk = 0, br = 0, bt = 0x7fffffff;
+        bool any = false;
+        for (int k = 0; k < beam; ++k) {
+            const int row = k * B + b;
+            const float base = score_in[row] - lse[row];
+            for (int r = 0; r < beam; ++r) {
+                if (used >> (k * beam + r) & 1ull) continue;
+                const float tot = base + cand_val[(int64_t)row * beam + r];
+                const int tok = cand_idx[(int64_t)row * beam + r];
+                // candidates are visited in (k asc, value desc / token asc) order: strict > keeps the first of a tie,
+                // except that equal totals inside one row must still prefer the lower token id
+                if (!any || tot > best || (tot == best && k == bk && tok < bt)) { best = tot; bk = k; br = r; bt = tok; any = true; }
+            }
+        }
+        used |= 1ull << (bk * beam + br);
+        const int o = j * B + b;
+        score_out[o] = best;
+        parents[o] = bk;
+        tokens[o] = bt;
+        next_ids[o] = bt;
+        gather_rows[o] = bk * B + b;
+    }
+}
+extern "C" int capmi_beam_step(const float* logits, int V, int ld, int B, int beam, const float* score_in, float* score_out,
+                               float* cand_val, int* cand_idx, float* lse, int* parents, int* tokens, int64_t* next_ids,
+                               int* gather_rows, void* stream) {
+    CAPMI_CHECK(logits && score_in && score_out && cand_val && cand_idx && lse && parents && tokens && next_ids && gather_rows,
+                "capmi_beam_step: null pointer");
+    CAPMI_CHECK(beam >= 1 && beam <= 8 && B >= 1 && V >= 1, "capmi_beam_step: beam=%d (1..8), B=%d, V=%d", beam, B, V);
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(beam * B), dim3(256), 0, (hipStream_t)stream, logits, V, ld, beam, cand_val, cand_idx, lse);
+    hipLaunchKernelGGL(beam_select_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx, lse, score_in, B, beam,
+                       score_out, parents, tokens, next_ids, gather_rows);
+    CAPMI_LAUNCH_CHECK("capmi_beam_step");
+    return 0;
+}
+// dst[r][:] = src[rows[r]][:]  (hidden / cell state of the surviving hypotheses)
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ src, const int* __restrict__ rows, T* dst, int n, int cpr) {
+    constexpr int VEC = Vec<T>::N;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * cpr) return;
+    const int r = e / cpr, cc = e % cpr;
+    vstore<T>(dst + ((int64_t)r * cpr + cc) * VEC, vload<T>(src + ((int64_t)rows[r] * cpr + cc) * VEC));
+}
+extern "C" int capmi_gather_rows(const void* src, const int* rows, void* dst, int n, int H, int dtype, void* stream) {
+    CAPMI_CHECK(src && rows && dst, "capmi_gather_rows: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_gather_rows", {
+        CAPMI_CHECK(H % Vec<T>::N == 0, "capmi_gather_rows: H not a multiple of the vector width");
+        const int cpr = H / Vec<T>::N;
+        hipLaunchKernelGGL(gather_rows_kernel<T>, dim3(cdiv((int64_t)n * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)src, rows, (T*)dst, n, cpr);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_gather_rows");
+    return 0;
+}
+// ids[b][t] (float32, quirk Q2) of the best final hypothesis (rank 0), walking the parents back from the last step
+__global__ __launch_bounds__(64) void beam_backtrack_kernel(const int* __restrict__ tokens, const int* __restrict__ parents, float* out, int Ti, int B, int beam) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    int j = 0;
+    for (int t = Ti - 1; t >= 0; --t) {
+        const int o = (t * beam + j) * B + b;
+        out[(int64_t)b * Ti + t] = (float)tokens[o];
+        j = parents[o];
+    }
+}
+extern "C" int capmi_beam_backtrack(const int* tokens, const int* parents, float* out_ids_f32, int Ti, int B, int beam, void* stream) {
+    CAPMI_CHECK(tokens && parents && out_ids_f32, "capmi_beam_backtrack: null pointer");
+    hipLaunchKernelGGL(beam_backtrack_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, tokens, parents, out_ids_f32, Ti, B, beam);
+    CAPMI_LAUNCH_CHECK("capmi_beam_backtrack");
+    return 0;
+}
+
 // ------------------------------------------------------------------ column sums (bias gradients)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, int M, int N, int lda, float* out, ColLayout L) {

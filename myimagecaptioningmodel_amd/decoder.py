@@ -332,3 +332,45 @@ class DecoderRunner:
             plan.add('capmi_lstm_cell_fwd', _p(self.G), cp, hn, cn, B, H, code)
             self._plan_post_lstm(plan, W, B, _p(self.X), hp, hn, cn)
             plan.add('capmi_argmax', _p(self.logits), _p(self.ids), _p(out_ids_f32) + t * 4, Ti, B, self.V, self.Vld)  # :120-123
+
+    def plan_beam(self, plan, A, W, out_ids_f32, Ti, beam):
+        """Beam-search decode (build-defined extension, oracle/model.py beam_decode): the greedy loop on beam*B rows
+        (row k*B + b = hypothesis k of image b; this runner is built with T = beam so its per-step buffers hold
+        them), plus per step capmi_beam_step (keep the `beam` best continuations per image) and a gather of the
+        surviving hypotheses' (h, c).  The caller fills self.ids[:beam*B] with start_idx and self.beam_score[0]."""
+        st, B, H, E = self.store, self.B, self.H, self.E
+        assert self.T >= beam and 1 <= beam <= 8
+        code = self.code
+        es = self.X.element_size()
+        R = beam * B
+        dev = self.X.device
+        z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
+        self.beam_h = [z((R, H), self.tdt) for _ in range(2)]       # [0] = state fed to the step, [1] = state it produces
+        self.beam_c = [z((R, H), self.tdt) for _ in range(2)]
+        self.beam_score = [z((beam, B), torch.float32) for _ in range(2)]
+        self.beam_cand_val, self.beam_cand_idx = z((R, beam), torch.float32), z((R, beam), torch.int32)
+        self.beam_lse, self.beam_rows = z((R,), torch.float32), z((R,), torch.int32)
+        self.beam_parents, self.beam_tokens = z((Ti, beam, B), torch.int32), z((Ti, beam, B), torch.int32)
+        self._plan_bridge(plan, A, W)
+        plan.add('capmi_bcast_rows', _p(self.g), _p(self.X), beam, B, H, E + H, E, code)
+        lw = W('lstm_w')
+        ldl = E + 2 * H
+        wh = _p(lw) + (E + H) * es
+        hp, cp, hn, cn = _p(self.beam_h[0]), _p(self.beam_c[0]), _p(self.beam_h[1]), _p(self.beam_c[1])
+        plan.add('capmi_fill_f32', hp, 0.0, R * H * es // 4)         # h_{-1} = c_{-1} = 0 (:63)
+        plan.add('capmi_fill_f32', cp, 0.0, R * H * es // 4)
+        for t in range(Ti):
+            sin, sout = self.beam_score[t % 2], self.beam_score[(t + 1) % 2]
+            plan.add('capmi_embedding_fwd', _p(self.ids), _p(W('word_embedding')), _p(self.X), R, E, self.V, E + H, self.pad, code)
+            self._gemm(plan, _p(self.X), R, E + H, _p(lw), 4 * H, _p(self.G), ldw=ldl, bias=_p(st.view('lstm_b')))
+            self._gemm(plan, hp, R, H, wh, 4 * H, _p(self.G), ldw=ldl, addend=_p(self.G), ld_add=4 * H)
+            plan.add('capmi_lstm_cell_fwd', _p(self.G), cp, hn, cn, R, H, code)
+            self._plan_post_lstm(plan, W, R, _p(self.X), hp, hn, cn)
+            off = t * beam * B * 4
+            plan.add('capmi_beam_step', _p(self.logits), self.V, self.Vld, B, beam, _p(sin), _p(sout), _p(self.beam_cand_val),
+                     _p(self.beam_cand_idx), _p(self.beam_lse), _p(self.beam_parents) + off, _p(self.beam_tokens) + off,
+                     _p(self.ids), _p(self.beam_rows))
+            plan.add('capmi_gather_rows', hn, _p(self.beam_rows), hp, R, H, code)      # survivors' state feeds the next step
+            plan.add('capmi_gather_rows', cn, _p(self.beam_rows), cp, R, H, code)
+        plan.add('capmi_beam_backtrack', _p(self.beam_tokens), _p(self.beam_parents), _p(out_ids_f32), Ti, B, beam)
+        self.beam_final_score = self.beam_score[Ti % 2]

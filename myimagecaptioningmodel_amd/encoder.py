@@ -188,9 +188,10 @@ class EncoderRunner:
         return self.grad[self.out_id]
 
     # ------------------------------------------------------------------ forward plan
-    def plan_forward(self, plan, image, weights, update_running=True):
+    def plan_forward(self, plan, image, weights, update_running=True, is_test=False):
         """image: f32 NCHW [B,3,S,S] device tensor (the reference feed).  weights(name) -> tensor
-        the kernels read (f32 master or bf16 shadow)."""
+        the kernels read (f32 master or bf16 shadow).  is_test: normalise with the running statistics (the exported
+        inference model, infer.py) instead of the batch statistics (every in-training graph, quirks Q3/Q4)."""
         st, B, code = self.store, self.B, self.code
         # a projection shortcut (conv + BN whose output only feeds a fused add) is independent of the
         # branch2a..2c chain of its block: side lane, joined before the bn_apply that adds it
@@ -220,19 +221,24 @@ class EncoderRunner:
                     plan.add('capmi_s2d_stem', _p(image), _p(self.s2d), B, op.cin, self.S, self.S, op.pad, self.stem_hb, self.stem_wb,
                              self.stem_cs, code)
                     plan.add('capmi_igemm_nt', _p(self.s2d), _p(w), _p(raw), self._stem_geom(op), c, self.kpad_of(op), c, None, None, 0, None, 0,
-                             _p(bn['stats']), 0, 0, 0, code)
+                             None if is_test else _p(bn['stats']), 0, 0, 0, code)
                 elif op.groups > 1:
                     hi, wi, _ = self.shape[op.src]
                     plan.add('capmi_dwconv3x3_fwd', _p(self.act[op.src]), _p(w), _p(raw), B, hi, wi, c, op.stride, ho, wo, code)
-                    plan.add('capmi_bn_stats', _p(raw), M, c, _p(bn['stats']), code)
+                    if not is_test:
+                        plan.add('capmi_bn_stats', _p(raw), M, c, _p(bn['stats']), code)
                 else:
                     g = self._conv_geom(op)
                     K = op.k * op.k * op.cin
                     plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
-                             _p(bn['stats']), 0, 0, 0, code, lane=ln)
-                plan.add('capmi_bn_finalize', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')),
-                         _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS,
-                         _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, lane=ln)
+                             None if is_test else _p(bn['stats']), 0, 0, 0, code, lane=ln)
+                if is_test:
+                    plan.add('capmi_bn_inference_coef', _p(st.view(op.name + '_bn_scale')), _p(st.state[op.name + '_bn_mean']),
+                             _p(st.state[op.name + '_bn_variance']), BN_EPS, _p(bn['mean']), _p(bn['a']), c, lane=ln)
+                else:
+                    plan.add('capmi_bn_finalize', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')),
+                             _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS,
+                             _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, lane=ln)
                 offset = _p(st.view(op.name + '_bn_offset'))
                 fa = self.fused_add.get(op.dst)
                 if fa is None:

@@ -182,23 +182,27 @@ class CaptionEngine:
         prog = dict(B=B, enc=enc, dec=dec, image=image, fwd=fwd, fwd_parts=[fwd_enc, fwd_dec], bwd=bwd, graph=None, marks=marks, n_dec=n_dec)
         return prog
 
-    def _compile_eval(self, B):
+    def _compile_eval(self, B, beam=1, is_test=False):
         cfg, S = self.cfg, self.cfg['image_size']
         enc = EncoderRunner(self.store, B, S, self.code, self.tdt, False)
         enc.overlap_forward = False         # one lane: the whole decode (encoder + Ti sequential steps) replays from a hipGraph
         K = enc.shape[enc.out_id][0] * enc.shape[enc.out_id][1]
         Ti = cfg['infer_max_length']
-        dec = DecoderRunner(self.store, B, K, 1, self.code, self.tdt, self.slots, False)
+        dec = DecoderRunner(self.store, B, K, max(1, beam), self.code, self.tdt, self.slots, False)
         image = torch.zeros((B, 3, S, S), dtype=torch.float32, device=self.device)
         out = torch.zeros((B, Ti), dtype=torch.float32, device=self.device)
         plan = Plan()
-        # in-training eval graph: batch statistics AND running-stat update (quirk Q3)
-        enc.plan_forward(plan, image, self.W, update_running=True)
-        es = dec.Hbuf.element_size()
-        plan.add('capmi_fill_f32', _p(dec.Hbuf), 0.0, B * dec.H * es // 4)
-        plan.add('capmi_fill_f32', _p(dec.Cbuf), 0.0, B * dec.H * es // 4)
-        dec.plan_greedy(plan, enc.out_tensor(), self.W, out, Ti)
-        return dict(B=B, enc=enc, dec=dec, image=image, out=out, plan=plan, graph=None)
+        # in-training eval graph: batch statistics AND running-stat update (quirk Q3); is_test: the exported
+        # inference model (infer.py) -- running statistics, nothing updated
+        enc.plan_forward(plan, image, self.W, update_running=not is_test, is_test=is_test)
+        if beam <= 1:
+            es = dec.Hbuf.element_size()
+            plan.add('capmi_fill_f32', _p(dec.Hbuf), 0.0, B * dec.H * es // 4)
+            plan.add('capmi_fill_f32', _p(dec.Cbuf), 0.0, B * dec.H * es // 4)
+            dec.plan_greedy(plan, enc.out_tensor(), self.W, out, Ti)
+        else:
+            dec.plan_beam(plan, enc.out_tensor(), self.W, out, Ti, beam)
+        return dict(B=B, enc=enc, dec=dec, image=image, out=out, plan=plan, graph=None, beam=beam)
 
     def _run_captured(self, prog, key, plans):
         """Replays `plans` from a hipGraph captured on first use (static shapes and pointers).
@@ -404,21 +408,33 @@ class CaptionEngine:
         self.refresh_shadows()
         return loss, lr
 
-    def decode(self, image):
-        """Greedy decode of the in-training eval graph: float32 ids [B, infer_max_length]."""
+    def decode(self, image, beam=1, is_test=False):
+        """Decode of the eval graph: float32 ids [B, infer_max_length] (quirk Q2).  beam = 1: the reference's greedy
+        loop (:119-123); beam > 1: beam search (build-defined, see DecoderRunner.plan_beam), best hypothesis
+        returned.  is_test: batch norm on the running statistics, as in the exported inference model (infer.py);
+        the default is the in-training eval graph (batch statistics, running stats updated: quirk Q3)."""
         B = int(image.shape[0])
-        prog = self._eval.get(B)
+        key = (B, int(beam), bool(is_test))
+        prog = self._eval.get(key)
         if prog is None:
-            prog = self._eval[B] = self._compile_eval(B)
+            prog = self._eval[key] = self._compile_eval(B, int(beam), bool(is_test))
         if self.shadows_dirty:
             self.refresh_shadows()
         img = self._as_tensor(image, torch.float32, self.device)
         if tuple(img.shape) != tuple(prog['image'].shape):
             raise ValueError('image feed must be %s, got %s' % (tuple(prog['image'].shape), tuple(img.shape)))
         prog['image'].copy_(img)
-        prog['dec'].ids[:B].fill_(self.cfg['start_idx'])                   # :56-58
+        dec = prog['dec']
+        dec.ids[:max(1, beam) * B].fill_(self.cfg['start_idx'])                   # :56-58
+        if beam > 1:
+            dec.beam_score[0].fill_(-1e30)
+            dec.beam_score[0][0].zero_()
         self._run_captured(prog, 'graph', [prog['plan']])
         return prog['out']
+
+    def decode_scores(self, B, beam):
+        """Scores (sum of log-probabilities) of the best hypothesis of the last beam decode of this shape."""
+        return self._eval[(B, int(beam), False)]['dec'].beam_final_score[0]
 
 
 class ImageCaptionModel:

@@ -346,3 +346,62 @@ class OracleModel:
             out.append(word.astype(np.float32))
             all_logits.append(logits)
         return np.stack(out, axis=1), np.stack(all_logits, axis=1)
+
+    def beam_decode(self, image, beam, is_test=False, update_stats=True):
+        """Beam-search decode (BUILD-DEFINED extension, BASELINE cfg 5; the reference only has the greedy
+        loop).  Semantics chosen so that beam = 1 IS greedy_decode: fixed infer_max_length steps, no early
+        stop and no special casing of <stop> (quirk Q5 carried over; the caller truncates with ids_to_tokens),
+        score = sum of log-softmax probabilities, no length normalisation.  Every step keeps the `beam` best
+        of the beam x V continuations per image; ties go to the lower beam index, then the lower token id.
+        Hypothesis 0 starts with score 0, the others with -1e30 (all beams hold <start>).  Returns
+        (ids float32 [B, Ti] of the best final hypothesis, its score [B], per-step gap [Ti, B] between the
+        beam-th and (beam+1)-th candidate -- the tests' near-tie guard)."""
+        p, cfg = self.p, self.cfg
+        dt = self.dtype
+        t, _ = self._encoder_fwd(image.astype(dt), is_test=is_test, update_stats=update_stats)
+        A, V0, Amean, g = self._bridge_fwd(t[self.enc_out])
+        Vt = np.tanh(ops.fc_fwd(V0, p[FC_IMG_FEAT + '.w_0'], p[FC_IMG_FEAT + '.b_0']))
+        Ve = ops.fc_fwd(V0, p[FC_IMG_FEAT_EMB + '.w_0'], p[FC_IMG_FEAT_EMB + '.b_0'])
+        B, Ti, V = image.shape[0], cfg['infer_max_length'], cfg['vocab']
+        rep = lambda x: np.concatenate([x] * beam, axis=0)                # rows k*B + b (beam-major)
+        g_, Vt_, Ve_ = rep(g), rep(Vt), rep(Ve)
+        hid = np.zeros((beam * B, cfg['hidden']), dt)
+        cell = np.zeros((beam * B, cfg['hidden']), dt)
+        word = np.full((beam * B,), cfg['start_idx'], np.int64)
+        score = np.full((beam, B), -1e30, np.float64)
+        score[0] = 0.0
+        tokens, parents, gaps = [], [], []
+        for _ in range(Ti):
+            hid, cell, logits, _c = self._step_fwd(word, g_, hid, cell, Vt_, Ve_)
+            lg = logits.astype(np.float64).reshape(beam, B, V)
+            m = lg.max(-1, keepdims=True)
+            logp = lg - (m + np.log(np.exp(lg - m).sum(-1, keepdims=True)))
+            tot = (score[:, :, None] + logp).transpose(1, 0, 2).reshape(B, beam * V)      # flat index k*V + v
+            order = np.argsort(-tot, axis=1, kind='stable')[:, :beam + 1]
+            best = order[:, :beam]
+            gaps.append(np.take_along_axis(tot, order[:, beam - 1:beam], 1)[:, 0] - np.take_along_axis(tot, order[:, beam:beam + 1], 1)[:, 0])
+            par, tok = best // V, best % V                                                 # [B, beam]
+            score = np.take_along_axis(tot, best, 1).T.copy()                              # [beam, B]
+            src = (par.T * B + np.arange(B)[None, :]).reshape(-1)                          # row of the parent state
+            hid, cell = hid[src], cell[src]
+            word = tok.T.reshape(-1).astype(np.int64)
+            tokens.append(tok.T.copy())
+            parents.append(par.T.copy())
+        out = np.zeros((B, Ti), np.float32)
+        j = np.zeros(B, np.int64)                                                          # best final hypothesis: rank 0
+        for s in reversed(range(Ti)):
+            out[:, s] = tokens[s][j, np.arange(B)]
+            j = parents[s][j, np.arange(B)]
+        return out, score[0].copy(), np.stack(gaps)
+
+
+def ids_to_tokens(ids, stop_idx=3, pad_idx=0):
+    """Host-side filter of evaluate.py:15-25 / infer.py: a caption is the ids up to (not including) the first
+    <stop>, with <pad> ids skipped.  ids: one row of the float32 [B, Ti] decode output."""
+    out = []
+    for v in np.rint(np.asarray(ids)).astype(np.int64).tolist():      # float32 ids are rounded first (evaluate.py:30-33)
+        if v == stop_idx:
+            break
+        if v != pad_idx:
+            out.append(v)
+    return out

@@ -616,6 +616,59 @@ def test_attention_fwd_bwd(dtype, slots):
         check(host(db10_), ab.grad.numpy(), dtype, scale=1.0, name='db10')
 
 
+@pytest.mark.parametrize('B,beam,V', [(3, 4, 37), (70, 5, 1000), (2, 8, 9)])
+def test_beam_step_gather_backtrack(B, beam, V):
+    """capmi_beam_step / capmi_gather_rows / capmi_beam_backtrack against NumPy, with tied logits and tied totals:
+    ties go to the lower beam index, then the lower token id (stable descending sort of the flat [beam*V] totals)."""
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(B + beam + V)
+    ld = (V + 7) // 8 * 8
+    Ti = 3
+    logits = np.round(rng.standard_normal((Ti, beam * B, ld)) * 2) / 2          # coarse values: many exact ties
+    score = np.zeros((beam, B), np.float32)
+    score[1:] = rng.standard_normal((beam - 1, B)).astype(np.float32)
+    score[min(2, beam - 1)] = score[1] if beam > 2 else score[min(2, beam - 1)]   # two hypotheses with equal scores
+    f32, i32 = torch.float32, torch.int32
+    S = [dev(score, f32), torch.zeros((beam, B), dtype=f32, device=DEV)]
+    cv, ci = torch.zeros((beam * B, beam), dtype=f32, device=DEV), torch.zeros((beam * B, beam), dtype=i32, device=DEV)
+    lse, rows = torch.zeros(beam * B, dtype=f32, device=DEV), torch.zeros(beam * B, dtype=i32, device=DEV)
+    par, tok = torch.zeros((Ti, beam, B), dtype=i32, device=DEV), torch.zeros((Ti, beam, B), dtype=i32, device=DEV)
+    ids = torch.zeros(beam * B, dtype=torch.int64, device=DEV)
+    _KEEP.extend(S + [cv, ci, lse, rows, par, tok, ids])
+    sc = score.astype(np.float64)
+    want_par, want_tok = [], []
+    for t in range(Ti):
+        L = dev(logits[t], f32)
+        _lib.call('capmi_beam_step', p(L), V, ld, B, beam, p(S[t % 2]), p(S[(t + 1) % 2]), p(cv), p(ci), p(lse),
+                  par.data_ptr() + t * beam * B * 4, tok.data_ptr() + t * beam * B * 4, p(ids), p(rows), stream())
+        lg = logits[t][:, :V].astype(np.float32).astype(np.float64).reshape(beam, B, V)
+        m = lg.max(-1, keepdims=True)
+        logp = lg - (m + np.log(np.exp(lg - m).sum(-1, keepdims=True)))
+        tot = (sc[:, :, None] + logp).astype(np.float32).transpose(1, 0, 2).reshape(B, beam * V)
+        best = np.argsort(-tot, axis=1, kind='stable')[:, :beam]
+        sc = np.take_along_axis(tot, best, 1).T.astype(np.float64)
+        want_par.append((best // V).T)
+        want_tok.append((best % V).T)
+        got_rows, got_ids = host(rows).astype(np.int64), host(ids).astype(np.int64)
+        np.testing.assert_array_equal(got_ids.reshape(beam, B), want_tok[-1])
+        np.testing.assert_array_equal(got_rows.reshape(beam, B), want_par[-1] * B + np.arange(B)[None, :])
+        np.testing.assert_allclose(host(S[(t + 1) % 2]), sc, rtol=0, atol=1e-4)
+    out = torch.zeros((B, Ti), dtype=f32, device=DEV)
+    _lib.call('capmi_beam_backtrack', p(tok), p(par), p(out), Ti, B, beam, stream())
+    want = np.zeros((B, Ti))
+    j = np.zeros(B, np.int64)
+    for t in reversed(range(Ti)):
+        want[:, t] = want_tok[t][j, np.arange(B)]
+        j = want_par[t][j, np.arange(B)]
+    np.testing.assert_array_equal(host(out), want)
+    for dtype in ('f32', 'bf16'):
+        src = dev(rng.standard_normal((beam * B, 64)), tdt[dtype])
+        dst = torch.zeros_like(src)
+        _lib.call('capmi_gather_rows', p(src), p(rows), p(dst), beam * B, 64, code[dtype], stream())
+        torch.cuda.synchronize()
+        assert torch.equal(dst, src[rows.long()])
+
+
 @pytest.mark.parametrize('V', [50, 1000, 12295])
 def test_softmax_xent_argmax(V):
     _lib, tdt, code = _env()

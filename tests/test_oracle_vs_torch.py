@@ -157,3 +157,41 @@ def test_greedy_first_token_is_start_and_no_early_stop(tiny_cfg):
     cap = np.zeros_like(caption); cap[:, 0] = 2; cap[:, 1] = 5
     _, tl = om.OracleModel(cfg, params).forward_train(image, cap, update_stats=False)
     np.testing.assert_allclose(tl[:, 0], logits[:, 0], rtol=1e-9, atol=1e-9)
+
+
+def test_beam_search_restatement_properties():
+    """Beam search is a build-defined extension (the reference only has the greedy loop): its oracle is pinned by
+    properties -- beam = 1 is the greedy loop exactly; the best hypothesis' score is the sum of its tokens'
+    log-probabilities under teacher forcing; a wider beam never scores worse; the caption filter follows
+    evaluate.py:14-25."""
+    ocfg = om.default_cfg(encoder='mobilenetv2', image_size=64, hidden=24, embed=12, vocab=40, sentence_length=6,
+                          infer_max_length=6, attention='slots')
+    params = om.init_params(ocfg, seed=4, dtype=np.float64)
+    rng = np.random.RandomState(2)
+    image = rng.uniform(0, 1, (3, 3, 64, 64))
+    fresh = lambda: om.OracleModel(ocfg, {k: v.copy() for k, v in params.items()})
+    greedy, lg = fresh().greedy_decode(image)
+    b1, s1, _ = fresh().beam_decode(image, 1)
+    np.testing.assert_array_equal(b1, greedy)
+    prev = s1
+    for beam in (2, 4):
+        ids, score, gaps = fresh().beam_decode(image, beam)
+        assert np.all(score >= prev - 1e-9) and gaps.shape == (6, 3) and np.all(gaps >= 0)
+        prev = score
+        # re-score the returned hypothesis by teacher forcing through the step function
+        m = fresh()
+        t, _ = m._encoder_fwd(image, is_test=False, update_stats=False)
+        A, V0, Amean, g = m._bridge_fwd(t[m.enc_out])
+        Vt = np.tanh(om.ops.fc_fwd(V0, m.p[om.FC_IMG_FEAT + '.w_0'], m.p[om.FC_IMG_FEAT + '.b_0']))
+        Ve = om.ops.fc_fwd(V0, m.p[om.FC_IMG_FEAT_EMB + '.w_0'], m.p[om.FC_IMG_FEAT_EMB + '.b_0'])
+        hid = np.zeros((3, 24)); cell = np.zeros((3, 24)); word = np.full((3,), ocfg['start_idx'], np.int64)
+        tot = np.zeros(3)
+        for s in range(6):
+            hid, cell, logits, _ = m._step_fwd(word, g, hid, cell, Vt, Ve)
+            mx = logits.max(-1, keepdims=True)
+            logp = logits - (mx + np.log(np.exp(logits - mx).sum(-1, keepdims=True)))
+            word = ids[:, s].astype(np.int64)
+            tot += logp[np.arange(3), word]
+        np.testing.assert_allclose(tot, score, rtol=0, atol=1e-9)
+    assert om.ids_to_tokens(np.array([2., 9., 0., 4., 3., 8.])) == [2, 9, 4]
+    assert om.ids_to_tokens(np.array([3., 1.])) == []

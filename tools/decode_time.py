@@ -1,15 +1,28 @@
+"""Decode path timing (BASELINE cfg 5 shape: ResNet-50 encoder, V = 10000, Ti = 20): captions/s and per-batch latency
+(p50 over the timed batches) for the greedy loop and beam search.  usage: python tools/decode_time.py [B] [beam ...]"""
 import os, sys, time
+import numpy as np
 import torch
-sys.path.insert(0, '/root/repo' if os.path.exists('/root/repo/bench.py') else os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from myimagecaptioningmodel_amd import default_cfg
 from myimagecaptioningmodel_amd.model import CaptionEngine
-B = 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+beams = [int(x) for x in sys.argv[2:]] or [1, 5]
 cfg = default_cfg(batch_size=B, sample_count=0, **bench.WORKLOAD)
 eng = CaptionEngine(cfg, device='cuda:0', use_graph=True)
 image, cap = bench.synthetic_batch(B, cfg, 1234)
 image = torch.as_tensor(image).cuda()
-for _ in range(3): eng.decode(image)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): ids = eng.decode(image)
-torch.cuda.synchronize(); print('greedy decode B=64, T=20: %.2f ms/batch' % ((time.perf_counter() - t0) / 10 * 1e3), 'graph' if eng._eval[B].get('graph') else 'eager')
+for beam in beams:
+    for is_test in (False, True):
+        for _ in range(3):
+            eng.decode(image, beam=beam, is_test=is_test)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            ids = eng.decode(image, beam=beam, is_test=is_test)
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        p50 = float(np.median(lat))
+        print('B=%d beam=%d %s: p50 %.2f ms per batch, %.0f captions/s' % (B, beam, 'is_test ' if is_test else 'batch-BN', p50 * 1e3, B / p50))
