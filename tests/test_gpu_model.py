@@ -392,3 +392,30 @@ def test_inference_mode_decode_uses_running_statistics():
     assert not np.array_equal(ids_b, ids_o)
     assert ids_to_tokens(np.array([5., 0., 7., 3., 9.], np.float32)) == [5, 7]
     assert ids_to_tokens(ids_e[0]) == om.ids_to_tokens(ids_o[0])
+
+
+def test_device_feeder_on_gpu_feeds_identical_batches():
+    """Pinned double-buffered H2D feeder: device batches equal the host data in order (including the short last batch),
+    and a train step fed through it gives the loss of feeding the arrays directly."""
+    from myimagecaptioningmodel_amd.feeder import DeviceFeeder
+    ocfg, ecfg = _cfgs('mobilenetv2', 'slots', 'f32')
+    params, image, caption = _data(ocfg, 6, 23)
+    samples = [(image[i].astype(np.float16), caption[i]) for i in range(6)] * 3      # 18 samples -> batches 4,4,4,4,2
+
+    def batches():
+        for i in range(0, len(samples), 4):
+            yield samples[i:i + 4]
+
+    eng, ref = _engine(ecfg, params), _engine(ecfg, params)
+    n = 0
+    for k, (img_d, cap_d) in enumerate(DeviceFeeder(batches(), device='cuda:0', depth=2)):
+        host_img = np.stack([s[0] for s in samples[4 * k:4 * k + 4]]).astype(np.float32)
+        host_cap = np.stack([s[1] for s in samples[4 * k:4 * k + 4]])
+        assert img_d.is_cuda and tuple(img_d.shape) == host_img.shape
+        l1 = float(eng.train_step(img_d, cap_d)[0].cpu()[0])
+        l2 = float(ref.train_step(host_img, host_cap)[0].cpu()[0])
+        # same inputs, same weights: equal up to the f32 atomics' summation order, which Adam amplifies step by step
+        assert abs(l1 - l2) <= (1e-6 if k == 0 else 1e-3) * max(1.0, abs(l2)), (k, l1, l2)
+        np.testing.assert_array_equal(img_d.cpu().numpy(), host_img)
+        n += 1
+    assert n == 5

@@ -260,3 +260,44 @@ def test_plan_lanes_keep_a_valid_sequential_order():
     q = Plan()
     q.extend(p)
     assert q.has_lanes and len(q.launches()) == 3
+
+
+def test_device_feeder_keeps_the_reader_contract():
+    """reader.py:41-76: fixed sample order, batches of (image, caption) samples, a short last batch, fp16-stored
+    pixels widened to float32 -- served through the double-buffered feeder (CPU device here: same logic, no pinning)."""
+    import torch
+    from myimagecaptioningmodel_amd.feeder import DeviceFeeder, collate
+    rng = np.random.RandomState(0)
+    samples = [(rng.rand(3, 8, 8).astype(np.float16), np.arange(5) + i) for i in range(11)]
+
+    def batches(bs):
+        for i in range(0, len(samples), bs):
+            yield samples[i:i + bs]
+
+    for depth in (1, 2, 4):
+        # a handed-out batch aliases its slot's buffers: valid until the next batch is requested
+        out = [(i.clone(), c.clone()) for i, c in DeviceFeeder(batches(4), device='cpu', depth=depth)]
+        assert [tuple(o[0].shape) for o in out] == [(4, 3, 8, 8), (4, 3, 8, 8), (3, 3, 8, 8)]
+        assert all(o[0].dtype == torch.float32 and o[1].dtype == torch.int64 for o in out)
+        assert [o[1][:, 0].tolist() for o in out] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10]]
+        for i, o in enumerate(out):
+            want = np.stack([s[0] for s in samples[4 * i:4 * i + 4]]).astype(np.float32)
+            np.testing.assert_array_equal(o[0].numpy(), want)
+    img, cap = collate((np.zeros((2, 3, 4, 4), np.float32), np.ones((2, 6), np.int32)))     # pre-stacked form
+    assert img.shape == (2, 3, 4, 4) and cap.dtype == np.int64
+
+    def broken():
+        yield samples[:4]
+        raise IOError('store went away')
+
+    f = DeviceFeeder(broken(), device='cpu', depth=2)
+    assert tuple(next(f)[0].shape) == (4, 3, 8, 8)
+    with pytest.raises(IOError):                 # a reader failure surfaces at its position, not as a silent end
+        next(f)
+    with pytest.raises(StopIteration):
+        next(f)
+    f = DeviceFeeder(batches(4), device='cpu', depth=1)
+    next(f)
+    f.close()
+    f.worker.join(timeout=5)
+    assert not f.worker.is_alive()
