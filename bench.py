@@ -119,7 +119,7 @@ def main():
     B = args.batch
     cfg = default_cfg(batch_size=B * world, sample_count=0, **WORKLOAD)
     eng = CaptionEngine(cfg, device=dev, use_graph=not args.no_graph, process_group=pg)
-    trainer = dp.OverlappedTrainer(eng) if world > 1 else None
+    trainer = dp.OverlappedTrainer(eng) if pg is not None else None      # (CAPMI_FORCE_DP=1: the N > 1 path on one rank)
     image, cap = synthetic_batch(B, cfg, 1234 + rank)
     image_d = torch.as_tensor(image).to(dev)
     cap_d = torch.as_tensor(cap).to(dev)
@@ -196,7 +196,7 @@ def main():
         out['cpu_baseline'] = cpu_baseline(cfg)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if pg is not None:
         dist.barrier()
         dist.destroy_process_group()
 

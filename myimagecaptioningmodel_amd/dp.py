@@ -24,9 +24,11 @@ import torch.distributed as dist
 def init_process_group_from_env(backend=None):
     """RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT / LOCAL_RANK from the launcher."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world <= 1:
+    if world <= 1 and os.environ.get('CAPMI_FORCE_DP', '0') in ('', '0'):
         return None, 0, 1, 0
-    rank = int(os.environ['RANK'])
+    # CAPMI_FORCE_DP=1: a one-rank group, to run the N > 1 code path (RCCL calls, bucket streams) on a one-GPU box
+    os.environ.setdefault('MASTER_PORT', '29533')
+    rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', rank))
     if torch.cuda.is_available():
         local %= torch.cuda.device_count()          # rehearsal on a box with fewer GPUs than ranks
@@ -86,7 +88,8 @@ class OverlappedTrainer:
     def __init__(self, engine, bucket_bytes=32 << 20):
         self.eng = engine
         self.bucket_bytes = bucket_bytes
-        self.comm_stream = torch.cuda.Stream(device=engine.device) if engine.world > 1 else None
+        self.active = engine.world > 1 or (engine.pg is not None and os.environ.get('CAPMI_FORCE_DP', '0') not in ('', '0'))
+        self.comm_stream = torch.cuda.Stream(device=engine.device) if self.active else None
         self._progs = {}
 
     def _prepare(self, B):
@@ -118,7 +121,7 @@ class OverlappedTrainer:
 
     def train_step(self, image, caption):
         eng = self.eng
-        if eng.world <= 1:
+        if not self.active:
             return eng.train_step(image, caption)
         B = int(image.shape[0])
         P = self._progs.get(B)

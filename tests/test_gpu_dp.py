@@ -84,3 +84,45 @@ def test_two_ranks_overlapped_allreduce_equals_emulation():
         # Adam turns tiny gradient noise (atomic order) into +-lr flips on near-zero gradients: compare in L2
         d = np.linalg.norm(p[k] - res[0][3][k]) / np.linalg.norm(p[k])
         assert d < 2e-3, (k, d)
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', CAPMI_FORCE_DP='1')
+    import torch.distributed as dist
+    from myimagecaptioningmodel_amd import default_cfg, dp
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+    pg, r, w, _ = dp.init_process_group_from_env()                      # backend nccl = RCCL
+    assert dist.get_backend(pg) == 'nccl' and w == 1
+    eng = CaptionEngine(default_cfg(**KW), device='cuda:0', use_graph=True, process_group=pg)
+    trainer = dp.OverlappedTrainer(eng, bucket_bytes=64 << 10)
+    assert trainer.active
+    image, cap = _batch()
+    losses = [float(trainer.train_step(image, cap)[0].cpu()[0]) for _ in range(3)]
+    p = eng.export_reference_params()
+    q.put((losses, len(trainer._progs[4]['segs']), {k: p[k] for k in ('lstm_w', 'conv1_1_weights')}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_rccl_group_runs_the_bucketed_path():
+    """The N > 1 code path with real RCCL calls on the bucket stream (one-rank group: the sum is the identity), against
+    the single-process step: same losses, same parameters up to atomic-order noise."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    proc = ctx.Process(target=_rccl_worker, args=(port, q))
+    proc.start()
+    losses, nseg, params = q.get(timeout=900)
+    proc.join(timeout=900)
+    assert proc.exitcode == 0 and nseg >= 3
+    from myimagecaptioningmodel_amd import default_cfg
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+    eng = CaptionEngine(default_cfg(**KW), device='cuda:0', use_graph=True)
+    image, cap = _batch()
+    want = [float(eng.train_step(image, cap)[0].cpu()[0]) for _ in range(3)]
+    np.testing.assert_allclose(losses[:2], want[:2], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(losses, want, rtol=0, atol=1e-2)
+    p = eng.export_reference_params()
+    for k in ('lstm_w', 'conv1_1_weights'):
+        assert np.linalg.norm(p[k] - params[k]) / np.linalg.norm(p[k]) < 2e-3, k
