@@ -1531,32 +1531,50 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
 // instruction fills 4 rows.  ds_read_b64_tr_b16 touches 16 rows x 32 B per instruction, so the 16-byte
 // chunk c of row r sits at position c ^ f(r), f(r) = (r & 3) | ((r >> 3) & 3) << 2 (applied on the
 // SOURCE address of the DMA): the 16 rows of a transposing read then cover all 64 banks twice.
+// The reads are inline assembly on purpose: behind the builtin the compiler cannot tell the transposing read from the
+// LDS-DMA writes in flight and puts s_waitcnt vmcnt(0) in front of the first one -- the next stage's DMA then never
+// overlaps this stage's MFMAs (measured: kernel time = DMA time + compute time).  The caller waits on lgkmcnt itself
+// (tr_reads_done) before the first MFMA.
 __device__ __forceinline__ void load_frag_tr_swz(Frag<bf16>& f, const char* tile, int g, int col16, int i) {
-    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    typedef __attribute__((address_space(3))) char lds_char;
     const int fsw = (i >> 2) | (g << 2);
     const int bytecol = col16 * 2 + (i & 3) * 8;
     const char* p0 = tile + (8 * g + (i >> 2)) * 256 + ((((bytecol >> 4) ^ fsw) << 4) | (bytecol & 15));
-    const char* p1 = p0 + 4 * 256;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    const uint32_t a0 = (uint32_t)(uintptr_t)(lds_char*)p0;
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a0));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     f.v = __builtin_bit_cast(bf16x8, both);
 }
+__device__ __forceinline__ void tr_reads_done() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 
-__global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
-    // 8 waves: 2 (n) x 4 (k), each a 64 x 32 sub-tile -- the loop is bound by per-wave instruction issue
-    // and LDS/MFMA latency, so the same tile and LDS footprint is shared by twice the waves
+// ABL (tools/tn_ablate.hip only; the library instantiates 0): 1 = no MFMAs, 2 = no LDS reads either, 4 = no DMA.
+// KS = 1: 8 waves as 2 (n) x 4 (k), 64 x 32 each, every wave walks both k-steps of a stage (12 fragment reads per 16 MFMAs
+//         and wave: the transposing LDS reads, 96 KB per stage and CU, are what the loop waits for -- tools/tn_ablate).
+// KS = 2: 2 (k-step) x 2 (n) x 2 (k), 64 x 64 each, wave group g multiplies only k-step g of every stage (8 reads per
+//         16 MFMAs: a third of the LDS traffic); the two groups' accumulators meet in LDS before the epilogue.
+// PIPE: fragments double-buffered in registers -- iteration t issues the DMA of stage t + NST (into the slot whose
+//       fragments were just consumed into registers), reads the fragments of stage t + 1 and multiplies stage t: the LDS
+//       read latency sits under the MFMAs and a DMA has NST - 1 iterations to land.
+template <int ABL, int NST = 2, int KS = 1, bool PIPE = false>
+__global__ __launch_bounds__(512, (KS == 2 || PIPE) ? 1 : 2) void igemm_tn_glds_kernel(WGradArgs a) {
     typedef bf16 T;
-    constexpr int BNO = 128, BKO = 128, RM = 64, NST = 2;     // 64 reduction rows per stage: two MFMA k-steps per barrier
+    constexpr int BNO = 128, BKO = 128, RM = 64;              // 64 reduction rows per stage: two MFMA k-steps per barrier
     constexpr int OPB = RM * 256, STB = 2 * OPB;            // bytes per operand tile / per stage
-    constexpr int TN_ = 4, TK_ = 2;
+    constexpr int TN_ = 4, TK_ = KS == 2 ? 4 : 2;
+    static_assert(KS == 1 || NST * STB >= BNO * BKO * 4, "the accumulator exchange needs one f32 tile inside the ring");
     __shared__ __attribute__((aligned(1024))) char smem[NST * STB];
 
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ DY = (const T*)a.dy;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 2, wk = wave & 3;
+    const int wg = KS == 2 ? wave >> 2 : 0;                                  // k-step group
+    const int wn = KS == 2 ? (wave >> 1) & 1 : wave >> 2, wk = KS == 2 ? wave & 1 : wave & 3;
     const int tiles_k = (a.K + BKO - 1) / BKO;
     const int tiles = tiles_k * ((a.N + BNO - 1) / BNO);
     const int id = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -1619,33 +1637,112 @@ __global__ __launch_bounds__(512, 2) void igemm_tn_glds_kernel(WGradArgs a) {
     const int fr = lane & 15, fg = lane >> 4;
     const int nsteps = (m_end - m_begin + RM - 1) / RM;
     auto rows_of = [&](int step) { return step < nsteps ? m_begin + step * RM : m_end; };   // >= m_end: nothing to load
+    if constexpr (PIPE) {
+        constexpr int KPW = RM / 32 / KS, NDMA = 2 * (RM / 32);
+        Frag<T> afA[KPW][TN_], bfA[KPW][TK_], afB[KPW][TN_], bfB[KPW][TK_];
+        auto read_stage = [&](Frag<T> (&af)[KPW][TN_], Frag<T> (&bf)[KPW][TK_], int slot) {
 #pragma unroll
-    for (int p = 0; p < NST - 1; ++p) issue_stage(p, rows_of(p));
+            for (int ks = 0; ks < KPW; ++ks) {
+                const char* sk = smem + slot * STB + (KS == 2 ? wg : ks) * 8192;
+#pragma unroll
+                for (int i = 0; i < TN_; ++i) load_frag_tr_swz(af[ks][i], sk, fg, wn * 64 + i * 16, fr);
+#pragma unroll
+                for (int j = 0; j < TK_; ++j) load_frag_tr_swz(bf[ks][j], sk + OPB, fg, wk * (TK_ * 16) + j * 16, fr);
+            }
+        };
+        auto mma_stage = [&](Frag<T> (&af)[KPW][TN_], Frag<T> (&bf)[KPW][TK_]) {
+#pragma unroll
+            for (int ks = 0; ks < KPW; ++ks)
+#pragma unroll
+                for (int i = 0; i < TN_; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[ks][i], bf[ks][j]);
+        };
+#pragma unroll
+        for (int p = 0; p < NST; ++p) issue_stage(p, rows_of(p));
+        wait_vmcnt<(NST - 1) * NDMA>();                       // stage 0
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_stage(afA, bfA, 0);
+        int slot = 0;                                         // ring slot of stage t
+        // one iteration: stage t + 1 has landed everywhere and every wave holds stage t in registers (its slot is free)
+        auto step = [&](int t, Frag<T> (&afc)[KPW][TN_], Frag<T> (&bfc)[KPW][TK_], Frag<T> (&afn)[KPW][TN_], Frag<T> (&bfn)[KPW][TK_]) {
+            wait_vmcnt<(NST - 2) * NDMA>();                   // this thread's part of stage t + 1
+            tr_reads_done();                                  // the fragments of stage t are in registers
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_stage(slot, rows_of(t + NST));
+            slot = slot + 1 == NST ? 0 : slot + 1;
+            read_stage(afn, bfn, slot);
+            __builtin_amdgcn_sched_barrier(0);                // reads of t + 1 in flight before the MFMAs of t
+            mma_stage(afc, bfc);
+        };
+        for (int t = 0; t < nsteps; t += 2) {
+            step(t, afA, bfA, afB, bfB);
+            if (t + 1 < nsteps) step(t + 1, afB, bfB, afA, bfA);
+        }
+        tr_reads_done();                                      // the trailing (unused) fragment reads
+    } else {
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (!(ABL & 4)) issue_stage(p, rows_of(p));
     int slot = 0;
     for (int s = 0; s < nsteps; ++s) {
         wait_vmcnt<(NST - 2) * 2 * (RM / 32)>();              // this thread's part of stage s has landed
         __builtin_amdgcn_s_barrier();                         // ... everyone's; all waves are done with stage s-1
         asm volatile("" ::: "memory");
-        issue_stage(slot == 0 ? NST - 1 : slot - 1, rows_of(s + NST - 1));
+        if (!(ABL & 4)) issue_stage(slot == 0 ? NST - 1 : slot - 1, rows_of(s + NST - 1));
         const char* st = smem + slot * STB;
         slot = slot + 1 == NST ? 0 : slot + 1;
-        Frag<T> af[RM / 32][TN_], bf[RM / 32][TK_];
+        if (ABL & 2) continue;
+        constexpr int KPW = RM / 32 / KS;          // k-steps of a stage per wave
+        Frag<T> af[KPW][TN_], bf[KPW][TK_];
 #pragma unroll
-        for (int ks = 0; ks < RM / 32; ++ks) {
+        for (int ks = 0; ks < KPW; ++ks) {
+            const char* sk = st + (KS == 2 ? wg : ks) * 8192;
 #pragma unroll
-            for (int i = 0; i < TN_; ++i) load_frag_tr_swz(af[ks][i], st + ks * 8192, fg, wn * 64 + i * 16, fr);
+            for (int i = 0; i < TN_; ++i) load_frag_tr_swz(af[ks][i], sk, fg, wn * 64 + i * 16, fr);
 #pragma unroll
-            for (int j = 0; j < TK_; ++j) load_frag_tr_swz(bf[ks][j], st + OPB + ks * 8192, fg, wk * 32 + j * 16, fr);
+            for (int j = 0; j < TK_; ++j) load_frag_tr_swz(bf[ks][j], sk + OPB, fg, wk * (TK_ * 16) + j * 16, fr);
         }
         __builtin_amdgcn_sched_barrier(0);        // every transposing read of the stage in flight before the first MFMA
+        tr_reads_done();
+        if (ABL & 1) {                            // keep the reads alive without the matrix pipe
 #pragma unroll
-        for (int ks = 0; ks < RM / 32; ++ks)
+            for (int ks = 0; ks < KPW; ++ks) {
+#pragma unroll
+                for (int i = 0; i < TN_; ++i) acc[i][0][0] += (float)af[ks][i].v[0];
+#pragma unroll
+                for (int j = 0; j < TK_; ++j) acc[0][j][1] += (float)bf[ks][j].v[7];
+            }
+            continue;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KPW; ++ks)
 #pragma unroll
             for (int i = 0; i < TN_; ++i)
 #pragma unroll
                 for (int j = 0; j < TK_; ++j) mma16(acc[i][j], af[ks][i], bf[ks][j]);
     }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (KS == 2) {
+        // group 1 hands its accumulators to group 0 through the (now idle) ring: one 16-byte slot per lane and tile
+        __syncthreads();
+        f32x4* xch = reinterpret_cast<f32x4*>(smem) + (wave & 3) * (TN_ * TK_ * 64) + lane;
+        if (wg == 1) {
+#pragma unroll
+            for (int i = 0; i < TN_; ++i)
+#pragma unroll
+                for (int j = 0; j < TK_; ++j) xch[(i * TK_ + j) * 64] = acc[i][j];
+        }
+        __syncthreads();
+        if (wg == 1) return;
+#pragma unroll
+        for (int i = 0; i < TN_; ++i)
+#pragma unroll
+            for (int j = 0; j < TK_; ++j) acc[i][j] += xch[(i * TK_ + j) * 64];
+    }
     tn_epilogue<BNO, BKO, TN_, TK_>(a, acc, n0, k0, split, wn, wk, fr, fg);
 }
 
@@ -1722,7 +1819,7 @@ static int launch_tn(WGradArgs& a, float* ws, long long ws_bytes, hipStream_t st
                     (long long)splits * a.Np * a.Kp * 4);
         a.slab = ws;
     }
-    if constexpr (sizeof(T) == 2 && BNO == 128) hipLaunchKernelGGL(igemm_tn_glds_kernel, dim3(tiles * splits), dim3(512), 0, st, a);
+    if constexpr (sizeof(T) == 2 && BNO == 128) hipLaunchKernelGGL(igemm_tn_glds_kernel<0>, dim3(tiles * splits), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles * splits), dim3(256), 0, st, a);
     if (use_slab)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.Np / 32, a.Kp / 32), dim3(256), 0, st, ws, splits, a.Np, a.Kp, a.dw, a.N, a.K, a.lddw);
