@@ -238,3 +238,26 @@ def test_every_encoder_layer_in_situ_against_torch_matmul(monkeypatch):
         del cols, ref, raw, y, got, dy, dz, xhat, dy_ref
     print('in-situ layers checked', checked, 'worst relative L2 errors', worst)
     assert checked['conv'] == 53 and checked['wgrad'] >= 50 and checked['bn_bwd'] >= 50 and checked['dgrad'] >= 30
+
+
+def test_bf16_step_agrees_with_the_f32_engine_where_the_model_allows(full):
+    """Same weights, same batch, the f32 engine (register-staged exact-f32 MFMA kernels, a different code path) against
+    the bf16 one at full size: loss within the bf16 bound of test_gpu_model (5e-2), decoder / bridge gradients in the
+    same direction (the encoder's are not comparable end to end at random init, see the in-situ test)."""
+    from myimagecaptioningmodel_amd import default_cfg
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+    cfg, eng, image, cap, params = full
+    l16 = _loss(eng, image, cap)
+    g16 = eng.export_reference_grads()
+    wl = dict(bench.WORKLOAD, dtype='f32')
+    e32 = CaptionEngine(default_cfg(batch_size=B, sample_count=0, **wl), device='cuda:0', use_graph=False)
+    e32.load_reference_params(params)
+    l32 = _loss(e32, image, cap)
+    g32 = e32.export_reference_grads()
+    assert abs(l16 - l32) <= 5e-2, (l16, l32)
+    for k, bound in (('lstm_w', 0.995), ('word_embedding', 0.995), ('fc_1.w_0', 0.99), ('fc_0.w_0', 0.98), ('fc_7.w_0', 0.995),
+                     ('fc_11.w_0', 0.995), ('fc_12.w_0', 0.995), ('out_fc_bias', 0.995)):
+        a, b = g16[k].astype(np.float64).ravel(), g32[k].astype(np.float64).ravel()
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
+        assert cos > bound, (k, cos)
+        assert abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.05, (k, np.linalg.norm(a), np.linalg.norm(b))
