@@ -106,6 +106,12 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON result): libraries that write banners to fd 1 (RCCL prints its version
+    # block there when the first communicator is created) are diverted to stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from myimagecaptioningmodel_amd import default_cfg, dp, profiling
@@ -195,7 +201,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg)
     if rank == 0:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if pg is not None:
         dist.barrier()
         dist.destroy_process_group()

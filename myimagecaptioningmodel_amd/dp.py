@@ -46,9 +46,13 @@ def init_process_group_from_env(backend=None):
 
 class GradBuckets:
     """Contiguous [begin, end) element ranges of the flat gradient buffer, cut at `cut_points`
-    (element offsets where a backward segment ends) so that each bucket is >= bucket_bytes."""
+    (element offsets where a backward segment ends) so that each bucket is >= bucket_bytes.
 
-    def __init__(self, total, cut_points, bucket_bytes=32 << 20, elem_bytes=4):
+    The LAST bucket's all-reduce is the only one nothing can hide (backward has ended): it is cut down to the
+    smallest tail of >= tail_bytes that the cut points allow (the early encoder layers, whose gradients come last,
+    hold few parameters), instead of whatever remainder the greedy pass leaves (up to 2 x bucket_bytes)."""
+
+    def __init__(self, total, cut_points, bucket_bytes=32 << 20, elem_bytes=4, tail_bytes=2 << 20):
         cuts = sorted(set(c for c in cut_points if 0 < c < total)) + [total]
         self.ranges = []
         begin = 0
@@ -57,6 +61,12 @@ class GradBuckets:
                 if c > begin:
                     self.ranges.append((begin, c))
                 begin = c
+        if self.ranges and tail_bytes:
+            b, e = self.ranges[-1]
+            inner = [c for c in cuts if b < c < e and (e - c) * elem_bytes >= tail_bytes]
+            if inner and (e - b) * elem_bytes > 2 * tail_bytes:
+                c = inner[-1]                      # the latest cut that still leaves tail_bytes
+                self.ranges[-1:] = [(b, c), (c, e)]
 
     def __iter__(self):
         return iter(self.ranges)

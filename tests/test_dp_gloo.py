@@ -93,3 +93,6 @@ def test_grad_buckets_cut_only_at_segment_boundaries():
     b = dp.GradBuckets(1000, [100, 250, 400, 900], bucket_bytes=4 * 300, elem_bytes=4)
     assert b.ranges == [(0, 400), (400, 900), (900, 1000)]
     assert dp.GradBuckets(10, [], bucket_bytes=1 << 20).ranges == [(0, 10)]
+    # the last bucket (its all-reduce is exposed) shrinks to the smallest tail of >= tail_bytes the cuts allow
+    t = dp.GradBuckets(1000, [100, 250, 400, 900, 950, 990], bucket_bytes=4 * 300, elem_bytes=4, tail_bytes=4 * 40)
+    assert t.ranges == [(0, 400), (400, 900), (900, 950), (950, 1000)]
