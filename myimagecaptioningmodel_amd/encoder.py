@@ -71,7 +71,7 @@ class EncoderRunner:
         self.code, self.tdt = dtype_code, torch_dtype
         self.dev = store.device
         self.need_backward = need_backward
-        self.fuse_bn_reduce = False     # BN backward sums from the dgrad epilogue (capmi_igemm_nt_bnred): measured slower than the streaming reduce
+        self.fuse_bn_reduce = os.environ.get('CAPMI_BNRED', '0') == '1'     # BN backward sums from the dgrad epilogue (capmi_igemm_nt_bnred): measured slower than the streaming reduce
         enc = self.enc
         # ---- fold `add` ops into the bn_apply of the conv that produces their second operand
         consumers = {}

