@@ -1,0 +1,21 @@
+#!/bin/bash
+# Regenerates the profiles/ set on the GPU box (run through gpurun from the repo root):
+#   tools/refresh_profiles.sh r01        -> gpurun_out/prof_r01/*, copied into profiles/ by hand afterwards
+# Four separate rocprofv3 runs of bench.py: kernel statistics (with the roofline passes), a kernel trace without
+# them (timeline / per-shape / per-queue tables), and the two PMC passes (counters on their own, kernel trace only).
+set -euo pipefail
+tag="${1:-r01}"
+out="gpurun_out/prof_$tag"
+rm -rf "$out"; mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
+cp "$(ls $out/stats/*/*kernel_stats.csv | head -1)" "$out/${tag}_bench_kernel_stats.csv"
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > "$out/bench_trace.json" 2> "$out/trace.err"
+python3 tools/trace_by_shape.py "$out/trace" > "$out/${tag}_kernel_time_by_shape.txt"
+python3 tools/trace_overlap.py "$out/trace" > "$out/${tag}_timeline_two_streams.txt"
+python3 tools/trace_by_queue.py "$out/trace" > "$out/${tag}_kernel_time_by_queue.txt"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.err"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > "$out/pmc_write.json" 2> "$out/pmc_write.err"
+python3 tools/pmc_summary.py "$out/pmc_fetch" "$out/pmc_write" "$out/${tag}_pmc_traffic.json" "3 steps, two lanes"
+rm -rf "$out/stats" "$out/trace" "$out/pmc_fetch" "$out/pmc_write"
+ls -la "$out"
