@@ -651,6 +651,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IGemmArgs a) {
 // __syncthreads() in the loop (it would drain the DMA queue).
 __device__ __attribute__((aligned(64))) unsigned int capmi_zero_page[16];
 
+#ifndef CAPMI_NT_ABL
+#define CAPMI_NT_ABL 0
+#endif
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // KG = 2 / 4: 8 / 16 waves in KG k-groups -- group g takes the k-steps s with s % KG == g (its own part of every ring slot)
@@ -759,17 +762,20 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         boff[j] = AOPB + row * 64 + ((fg ^ ((row >> 2) & 3)) << 4);
     }
 
+    // CAPMI_NT_ABL (tools/nt_ablate.hip only, 0 in the library): 1 = no MFMAs, 2 = no LDS reads either, 4 = no DMA
 #pragma unroll
-    for (int p = 0; p < NST - 1; ++p) issue_stage(p);
+    for (int p = 0; p < NST - 1; ++p)
+        if (!(CAPMI_NT_ABL & 4)) issue_stage(p);
     int slot = 0;                                            // ring slot of stage kt
     for (int kt = 0; kt < nkt; ++kt) {
         // this thread's part of stage kt has landed (the (NST-2)*NGL younger DMAs may still be in flight)
         wait_vmcnt<(NST - 2) * NGL>();
         __builtin_amdgcn_s_barrier();                        // ... and everyone else's; all waves left stage kt-1
         asm volatile("" ::: "memory");
-        issue_stage(slot == 0 ? NST - 1 : slot - 1);         // refill the slot that was read in iteration kt-1
+        if (!(CAPMI_NT_ABL & 4)) issue_stage(slot == 0 ? NST - 1 : slot - 1);         // refill the slot that was read in iteration kt-1
         const char* st = smem + (slot * KG + grp) * STB;
         slot = slot + 1 == NST ? 0 : slot + 1;
+        if (CAPMI_NT_ABL & 2) continue;
         Frag<T> af[TM], bf[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i].load(reinterpret_cast<const T*>(st + aoff[i]));
@@ -779,6 +785,13 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         // per pair of MFMAs (the scheduler otherwise recycles two fragment registers; grids below ~2 waves per
         // SIMD have nobody to hide that behind)
         __builtin_amdgcn_sched_barrier(0);
+        if (CAPMI_NT_ABL & 1) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[i][0][0] += (float)af[i].v[0];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[0][j][1] += (float)bf[j].v[7];
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
