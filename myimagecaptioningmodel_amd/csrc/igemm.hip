@@ -305,60 +305,6 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += bias;
         }
     }
-    if (a.stats) {
-        // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) per column of this workgroup's
-        // BM-row block from the f32 accumulators.  Each wave reduces its RW rows in registers
-        // (two passes, no cancellation); the WMW wave results meet in LDS and are merged with Chan's
-        // formula; ONE part per workgroup row block is stored (plain stores, one producer per
-        // (part, column): deterministic).  bn_finalize (bn_ops.hip) merges the parts in f64.
-        // sred: [WMW][BN][2] floats of LDS scratch (the staging tiles are free now)
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float s1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (rows_full || i * 16 + fg * 4 + r < wcnt) s1 += acc[i][j][r];
-            const float mean = wcnt > 0 ? row4_sum(s1) / (float)wcnt : 0.f;
-            float m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d = acc[i][j][r] - mean;
-                    if (rows_full || i * 16 + fg * 4 + r < wcnt) m2 += d * d;
-                }
-            m2 = row4_sum(m2);
-            if (fg == 0) {
-                const int c = wn * WN + TN * fr + j;
-                sred[(wm * BN + c) * 2 + 0] = mean;
-                sred[(wm * BN + c) * 2 + 1] = m2;
-            }
-        }
-        __syncthreads();
-        if (tid < BN && n0 + tid < a.N && m0 < a.M) {
-            float ntot = 0.f, msum = 0.f;
-#pragma unroll
-            for (int w = 0; w < WMW; ++w) {
-                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
-                ntot += nw;
-                msum += nw * sred[(w * BN + tid) * 2];
-            }
-            const float mean = msum / ntot;
-            float m2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WMW; ++w) {
-                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
-                const float d = sred[(w * BN + tid) * 2] - mean;
-                m2 += sred[(w * BN + tid) * 2 + 1] + nw * d * d;
-            }
-            float* w = a.stats + ((int64_t)(m0 / BM) * a.N + n0 + tid) * 2;
-            w[0] = mean;
-            w[1] = m2;
-        }
-    }
     const T* addend = (const T*)a.addend;
     const T* ysaved = (const T*)a.ysaved;
     const bool vec_ok = (a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N &&
@@ -471,6 +417,62 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                     }
                 }
             }
+        }
+    }
+    if (a.stats) {
+        // (after the output stores have been issued: the statistics -- two LDS round trips -- then run while the stores
+        // drain; in front of them they cost +42 % on the write-bound 64 -> 256 1x1 layer, tools/nt_ablate.hip)
+        // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) per column of this workgroup's
+        // BM-row block from the f32 accumulators.  Each wave reduces its RW rows in registers
+        // (two passes, no cancellation); the WMW wave results meet in LDS and are merged with Chan's
+        // formula; ONE part per workgroup row block is stored (plain stores, one producer per
+        // (part, column): deterministic).  bn_finalize (bn_ops.hip) merges the parts in f64.
+        // sred: [WMW][BN][2] floats of LDS scratch (the staging tiles are free now)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (rows_full || i * 16 + fg * 4 + r < wcnt) s1 += acc[i][j][r];
+            const float mean = wcnt > 0 ? row4_sum(s1) / (float)wcnt : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = acc[i][j][r] - mean;
+                    if (rows_full || i * 16 + fg * 4 + r < wcnt) m2 += d * d;
+                }
+            m2 = row4_sum(m2);
+            if (fg == 0) {
+                const int c = wn * WN + TN * fr + j;
+                sred[(wm * BN + c) * 2 + 0] = mean;
+                sred[(wm * BN + c) * 2 + 1] = m2;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.N && m0 < a.M) {
+            float ntot = 0.f, msum = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) {
+                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
+                ntot += nw;
+                msum += nw * sred[(w * BN + tid) * 2];
+            }
+            const float mean = msum / ntot;
+            float m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) {
+                const float nw = (float)max(0, min(RW, a.M - (m0 + w * RW)));
+                const float d = sred[(w * BN + tid) * 2] - mean;
+                m2 += sred[(w * BN + tid) * 2 + 1] + nw * d * d;
+            }
+            float* w = a.stats + ((int64_t)(m0 / BM) * a.N + n0 + tid) * 2;
+            w[0] = mean;
+            w[1] = m2;
         }
     }
     if constexpr (RED)
