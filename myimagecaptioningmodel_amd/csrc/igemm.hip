@@ -1557,8 +1557,8 @@ __device__ __forceinline__ void load_frag_tr_swz(Frag<bf16>& f, const char* tile
     const char* p0 = tile + (8 * g + (i >> 2)) * 256 + ((((bytecol >> 4) ^ fsw) << 4) | (bytecol & 15));
     const uint32_t a0 = (uint32_t)(uintptr_t)(lds_char*)p0;
     s16x4 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(hi) : "v"(a0) : "memory");
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     f.v = __builtin_bit_cast(bf16x8, both);
