@@ -307,11 +307,15 @@ extern "C" int capmi_bn_inference_coef(const float* scale, const float* run_mean
 }
 
 // ------------------------------------------------------------------ apply: y = act(a*(x - mean) + offset (+ res))
-template <typename T>
+// ACT >= 0: compile-time activation (none / relu / relu6, what the encoders use); ACT < 0: the run-time code `act`.
+// U rows are loaded as one batch before any arithmetic (see bn_bwd_reduce_kernel: with the run-time switch in the loop
+// the compiler kept one or two loads in flight per thread).
+template <typename T, int ACT, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ ca,
                                                        const float* __restrict__ offset, const T* __restrict__ res, T* __restrict__ y,
                                                        int M, int C, int act, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
+    constexpr int U = 4;
     const int cc = threadIdx.x % L.cpc, rr = threadIdx.x / L.cpc;
     const int chunk = blockIdx.y * L.cpc + cc;
     if (rr >= L.rp || chunk * VEC >= C) return;
@@ -325,18 +329,44 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     }
     const int m_begin = blockIdx.x * L.rows_per_block;
     const int m_end = min(M, m_begin + L.rows_per_block);
-#pragma unroll 8
-    for (int m = m_begin + rr; m < m_end; m += L.rp) {
-        const int64_t off = (int64_t)m * C + chunk * VEC;
-        Vec<T> xv = vload<T>(x + off), rv, ov;
-        if (res) rv = vload<T>(res + off);
+    const int64_t step = (int64_t)L.rp * C;
+    auto one = [&](const Vec<T>& xv, const Vec<T>& rv) {
+        Vec<T> ov;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             float f = a[v] * (xv.get(v) - mu[v]) + b[v];
-            if (res) f += rv.get(v);
-            ov.set(v, apply_act(f, act));
+            if (RES) f += rv.get(v);
+            ov.set(v, apply_act(f, ACT >= 0 ? ACT : act));
         }
-        vstore<T>(y + off, ov);
+        return ov;
+    };
+    int m = m_begin + rr;
+    int64_t off = (int64_t)m * C + (int64_t)chunk * VEC;
+    for (; m + (U - 1) * L.rp < m_end; m += U * L.rp, off += U * step) {
+        Vec<T> xv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xv[u] = vload<T>(x + off + u * step);
+            if (RES) rv[u] = vload<T>(res + off + u * step);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) vstore<T>(y + off + u * step, one(xv[u], rv[u]));
+    }
+    for (; m < m_end; m += L.rp, off += step) {
+        Vec<T> xv = vload<T>(x + off), rv;
+        if (RES) rv = vload<T>(res + off);
+        vstore<T>(y + off, one(xv, rv));
+    }
+}
+
+template <typename T, bool RES>
+static void bn_apply_launch(int act, dim3 grid, hipStream_t st, const T* x, const float* mean, const float* ca, const float* offset, const T* res,
+                            T* y, int M, int C, const ColLayout& L) {
+    switch (act) {
+        case CAPMI_ACT_NONE: hipLaunchKernelGGL((bn_apply_kernel<T, CAPMI_ACT_NONE, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, M, C, act, L); break;
+        case CAPMI_ACT_RELU: hipLaunchKernelGGL((bn_apply_kernel<T, CAPMI_ACT_RELU, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, M, C, act, L); break;
+        case CAPMI_ACT_RELU6: hipLaunchKernelGGL((bn_apply_kernel<T, CAPMI_ACT_RELU6, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, M, C, act, L); break;
+        default: hipLaunchKernelGGL((bn_apply_kernel<T, -1, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, M, C, act, L); break;
     }
 }
 
@@ -347,8 +377,8 @@ extern "C" int capmi_bn_apply(const void* x, const float* saved_mean, const floa
         CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_apply: C=%d not a multiple of %d", C, Vec<T>::N);
         int gx, gy;
         ColLayout L = ew_layout(M, C, Vec<T>::N, &gx, &gy);
-        hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, saved_mean, coef_a, offset,
-                           (const T*)res, (T*)y, M, C, act, L);
+        if (res) bn_apply_launch<T, true>(act, dim3(gx, gy), (hipStream_t)stream, (const T*)x, saved_mean, coef_a, offset, (const T*)res, (T*)y, M, C, L);
+        else bn_apply_launch<T, false>(act, dim3(gx, gy), (hipStream_t)stream, (const T*)x, saved_mean, coef_a, offset, (const T*)res, (T*)y, M, C, L);
     });
     CAPMI_LAUNCH_CHECK("capmi_bn_apply");
     return 0;
@@ -359,11 +389,15 @@ extern "C" int capmi_bn_apply(const void* x, const float* saved_mean, const floa
 // Stage 2: red[0..C) += sum dz, red[C..2C) += sum dz*xhat over the partials (fixed order).
 // No global atomics: float atomics from every workgroup to the same cache line serialise at the
 // memory side (~17 ns each) and dominated this kernel; this form is also deterministic.
-template <typename T>
+// ACT is a template parameter and the loads of U rows are issued as one batch before any arithmetic: with a run-time
+// activation switch the loop compiled to a branch per element and 2-3 loads in flight per thread -- 2.8 TB/s on
+// cold tensors in the model (5.7 alone on MALL-warm ones), the largest kernel family on the main lane.
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, float* ws,
-                                                            int M, int C, int act, ColLayout L) {
+                                                            int M, int C, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
+    constexpr int U = ACT ? 4 : 6;                  // rows in flight per thread: U * (2 or 3) 16-byte loads
     __shared__ float part[256 * VEC];
     const int tid = threadIdx.x;
     const int cc = tid % L.cpc, rr = tid / L.cpc;
@@ -378,18 +412,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
         for (int v = 0; v < VEC; ++v) { mu[v] = mean[chunk * VEC + v]; is[v] = invstd[chunk * VEC + v]; }
         const int m_begin = blockIdx.x * L.rows_per_block;
         const int m_end = min(M, m_begin + L.rows_per_block);
-#pragma unroll 8
-        for (int m = m_begin + rr; m < m_end; m += L.rp) {
-            const int64_t off = (int64_t)m * C + chunk * VEC;
-            Vec<T> dv = vload<T>(dy + off), xv = vload<T>(x + off), yv;
-            if (act) yv = vload<T>(y + off);
+        const int64_t col = (int64_t)chunk * VEC, step = (int64_t)L.rp * C;
+        auto add_row = [&](const Vec<T>& dv, const Vec<T>& xv, const Vec<T>& yv) {
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
                 float dz = dv.get(v);
-                if (act) dz *= act_grad_from_out(yv.get(v), act);
+                if (ACT) dz *= act_grad_from_out(yv.get(v), ACT);
                 a1[v] += dz;
                 a2[v] += dz * (xv.get(v) - mu[v]) * is[v];
             }
+        };
+        int m = m_begin + rr;
+        int64_t off = (int64_t)m * C + col;
+        for (; m + (U - 1) * L.rp < m_end; m += U * L.rp, off += U * step) {
+            Vec<T> dv[U], xv[U], yv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                dv[u] = vload<T>(dy + off + u * step);
+                xv[u] = vload<T>(x + off + u * step);
+                if (ACT) yv[u] = vload<T>(y + off + u * step);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) add_row(dv[u], xv[u], yv[u]);
+        }
+        for (; m < m_end; m += L.rp, off += step) {
+            Vec<T> dv = vload<T>(dy + off), xv = vload<T>(x + off), yv;
+            if (ACT) yv = vload<T>(y + off);
+            add_row(dv, xv, yv);
         }
     }
     block_col_reduce<VEC>(part, a1, cc, rr, L, active);
@@ -441,6 +490,18 @@ extern "C" int capmi_bn_bwd_reduce_final(const float* ws, int nparts, int C, flo
     return 0;
 }
 
+template <typename T>
+static int bwd_reduce_launch(int act, int gx, int gy, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean, const float* invstd,
+                             float* ws, int M, int C, const ColLayout& L) {
+    switch (act) {
+        case CAPMI_ACT_NONE: hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, CAPMI_ACT_NONE>), dim3(gx, gy), dim3(256), 0, st, dy, x, y, mean, invstd, ws, M, C, L); return 0;
+        case CAPMI_ACT_RELU: hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, CAPMI_ACT_RELU>), dim3(gx, gy), dim3(256), 0, st, dy, x, y, mean, invstd, ws, M, C, L); return 0;
+        case CAPMI_ACT_RELU6: hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, CAPMI_ACT_RELU6>), dim3(gx, gy), dim3(256), 0, st, dy, x, y, mean, invstd, ws, M, C, L); return 0;
+    }
+    capmi_set_error("capmi_bn_bwd_reduce: unsupported activation %d", act);
+    return 1;
+}
+
 static ColLayout bwd_reduce_layout(int M, int C, int vec, int* gx, int* gy) {
     ColLayout L = ew_layout(M, C, vec, gx, gy);
     // fewer, deeper workgroups: 2 per CU keep the partial workspace and the second stage small
@@ -467,8 +528,7 @@ extern "C" int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y,
     CAPMI_DISPATCH(dtype, "capmi_bn_bwd_reduce", {
         CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_bwd_reduce: C=%d not a multiple of %d", C, Vec<T>::N);
         ColLayout L = bwd_reduce_layout(M, C, Vec<T>::N, &gx, &gy);
-        hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)x,
-                           (const T*)y, saved_mean, saved_invstd, ws, M, C, act, L);
+        if (bwd_reduce_launch<T>(act, gx, gy, (hipStream_t)stream, (const T*)dy, (const T*)x, (const T*)y, saved_mean, saved_invstd, ws, M, C, L)) return 1;
     });
     launch_bwd_reduce_final(ws, gx, C, red, (hipStream_t)stream);
     CAPMI_LAUNCH_CHECK("capmi_bn_bwd_reduce");
@@ -478,12 +538,15 @@ extern "C" int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y,
 // dx (+)= k1 * ((dz - m0) - (x - mu)*c2),  k1 = s*is, m0 = red0/M, c2 = is*red1/M;  dres (+)= dz.
 // Both differences are formed BEFORE scaling: a spatially uniform dz (e.g. the reference's
 // singleton attention) makes dz - mean(dz) cancel almost completely.
-template <typename T>
+// ACT: compile-time activation of the layer's output (none / relu / relu6); DRES: 0 = no residual gradient, 1 = store
+// dz, 2 = accumulate dz; DXACC: dx accumulates.  Batched loads as in bn_bwd_reduce_kernel.
+template <typename T, int ACT, int DRES, bool DXACC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ scale, const float* __restrict__ red, T* dx, int dx_acc,
-                                                           T* dres, int dres_acc, int M, int C, float inv_m, int act, ColLayout L) {
+                                                           const float* __restrict__ scale, const float* __restrict__ red, T* dx,
+                                                           T* dres, int M, int C, float inv_m, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
+    constexpr int U = (ACT ? 1 : 0) + (DRES == 2 ? 1 : 0) + (DXACC ? 1 : 0) >= 2 ? 2 : 4;      // register budget
     const int cc = threadIdx.x % L.cpc, rr = threadIdx.x / L.cpc;
     const int chunk = blockIdx.y * L.cpc + cc;
     if (rr >= L.rp || chunk * VEC >= C) return;
@@ -499,25 +562,69 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
     const int m_begin = blockIdx.x * L.rows_per_block;
     const int m_end = min(M, m_begin + L.rows_per_block);
-#pragma unroll 2
-    for (int m = m_begin + rr; m < m_end; m += L.rp) {
-        const int64_t off = (int64_t)m * C + chunk * VEC;
-        Vec<T> dv = vload<T>(dy + off), xv = vload<T>(x + off), yv, ov, rv, dxo, dro;
-        if (act) yv = vload<T>(y + off);
-        if (dx_acc) dxo = vload<T>(dx + off);
-        if (dres && dres_acc) dro = vload<T>(dres + off);
+    const int64_t step = (int64_t)L.rp * C;
+    auto one = [&](int64_t off, const Vec<T>& dv, const Vec<T>& xv, const Vec<T>& yv, const Vec<T>& dxo, const Vec<T>& dro) {
+        Vec<T> ov, rv;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             float dz = dv.get(v);
-            if (act) dz *= act_grad_from_out(yv.get(v), act);
+            if (ACT) dz *= act_grad_from_out(yv.get(v), ACT);
             float g = k1[v] * ((dz - m0[v]) - (xv.get(v) - mu[v]) * c2[v]);
-            if (dx_acc) g += dxo.get(v);
+            if (DXACC) g += dxo.get(v);
             ov.set(v, g);
-            if (dres) rv.set(v, dres_acc ? dz + dro.get(v) : dz);
+            if (DRES) rv.set(v, DRES == 2 ? dz + dro.get(v) : dz);
         }
         vstore<T>(dx + off, ov);
-        if (dres) vstore<T>(dres + off, rv);
+        if (DRES) vstore<T>(dres + off, rv);
+    };
+    int m = m_begin + rr;
+    int64_t off = (int64_t)m * C + (int64_t)chunk * VEC;
+    for (; m + (U - 1) * L.rp < m_end; m += U * L.rp, off += U * step) {
+        Vec<T> dv[U], xv[U], yv[U], dxo[U], dro[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t o = off + u * step;
+            dv[u] = vload<T>(dy + o);
+            xv[u] = vload<T>(x + o);
+            if (ACT) yv[u] = vload<T>(y + o);
+            if (DXACC) dxo[u] = vload<T>(dx + o);
+            if (DRES == 2) dro[u] = vload<T>(dres + o);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(off + u * step, dv[u], xv[u], yv[u], dxo[u], dro[u]);
     }
+    for (; m < m_end; m += L.rp, off += step) {
+        Vec<T> dv = vload<T>(dy + off), xv = vload<T>(x + off), yv, dxo, dro;
+        if (ACT) yv = vload<T>(y + off);
+        if (DXACC) dxo = vload<T>(dx + off);
+        if (DRES == 2) dro = vload<T>(dres + off);
+        one(off, dv, xv, yv, dxo, dro);
+    }
+}
+
+template <typename T, int ACT, int DRES>
+static void bn_bwd_apply_launch2(bool dxacc, dim3 grid, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean, const float* invstd,
+                                 const float* scale, const float* red, T* dx, T* dres, int M, int C, const ColLayout& L) {
+    if (dxacc) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, true>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, 1.f / (float)M, L);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, false>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, 1.f / (float)M, L);
+}
+template <typename T, int ACT>
+static void bn_bwd_apply_launch1(int dres_mode, bool dxacc, dim3 grid, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean,
+                                 const float* invstd, const float* scale, const float* red, T* dx, T* dres, int M, int C, const ColLayout& L) {
+    if (dres_mode == 0) bn_bwd_apply_launch2<T, ACT, 0>(dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L);
+    else if (dres_mode == 1) bn_bwd_apply_launch2<T, ACT, 1>(dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L);
+    else bn_bwd_apply_launch2<T, ACT, 2>(dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L);
+}
+template <typename T>
+static int bn_bwd_apply_launch(int act, int dres_mode, bool dxacc, dim3 grid, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean,
+                               const float* invstd, const float* scale, const float* red, T* dx, T* dres, int M, int C, const ColLayout& L) {
+    switch (act) {
+        case CAPMI_ACT_NONE: bn_bwd_apply_launch1<T, CAPMI_ACT_NONE>(dres_mode, dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L); return 0;
+        case CAPMI_ACT_RELU: bn_bwd_apply_launch1<T, CAPMI_ACT_RELU>(dres_mode, dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L); return 0;
+        case CAPMI_ACT_RELU6: bn_bwd_apply_launch1<T, CAPMI_ACT_RELU6>(dres_mode, dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L); return 0;
+    }
+    capmi_set_error("capmi_bn_bwd_apply: unsupported activation %d", act);
+    return 1;
 }
 
 extern "C" int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, const float* saved_mean, const float* saved_invstd,
@@ -529,9 +636,8 @@ extern "C" int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, 
         CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_bwd_apply: C=%d not a multiple of %d", C, Vec<T>::N);
         int gx, gy;
         ColLayout L = ew_layout(M, C, Vec<T>::N, &gx, &gy);
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)x, (const T*)y,
-                           saved_mean, saved_invstd, scale, red, (T*)dx, dx_accumulate, (T*)dres, dres_accumulate, M, C,
-                           1.f / (float)M, act, L);
+        if (bn_bwd_apply_launch<T>(act, dres ? (dres_accumulate ? 2 : 1) : 0, dx_accumulate != 0, dim3(gx, gy), (hipStream_t)stream, (const T*)dy,
+                                   (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, red, (T*)dx, (T*)dres, M, C, L)) return 1;
     });
     CAPMI_LAUNCH_CHECK("capmi_bn_bwd_apply");
     return 0;
