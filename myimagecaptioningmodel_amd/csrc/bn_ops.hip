@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, float* ws,
                                                             int M, int C, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
-    constexpr int U = ACT ? 4 : 6;                  // rows in flight per thread: U * (2 or 3) 16-byte loads
+    constexpr int U = 4;                            // rows per batch; two batches (U * (2 or 3) 16-byte loads each) in flight
     __shared__ float part[256 * VEC];
     const int tid = threadIdx.x;
     const int cc = tid % L.cpc, rr = tid / L.cpc;
@@ -422,19 +422,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                 a2[v] += dz * (xv.get(v) - mu[v]) * is[v];
             }
         };
+        // two register buffers: the loads of batch k + 1 are in flight while batch k is summed (2 workgroups per CU leave
+        // few other waves to hide them behind)
         int m = m_begin + rr;
         int64_t off = (int64_t)m * C + col;
-        for (; m + (U - 1) * L.rp < m_end; m += U * L.rp, off += U * step) {
-            Vec<T> dv[U], xv[U], yv[U];
+        Vec<T> dA[U], xA[U], yA[U], dB[U], xB[U], yB[U];
+        auto load = [&](Vec<T> (&dv)[U], Vec<T> (&xv)[U], Vec<T> (&yv)[U], int64_t o) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                dv[u] = vload<T>(dy + off + u * step);
-                xv[u] = vload<T>(x + off + u * step);
-                if (ACT) yv[u] = vload<T>(y + off + u * step);
+                dv[u] = vload<T>(dy + o + u * step);
+                xv[u] = vload<T>(x + o + u * step);
+                if (ACT) yv[u] = vload<T>(y + o + u * step);
             }
+        };
+        auto sum = [&](Vec<T> (&dv)[U], Vec<T> (&xv)[U], Vec<T> (&yv)[U]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) add_row(dv[u], xv[u], yv[u]);
+        };
+        const int nb = m < m_end ? (m_end - m + L.rp - 1) / L.rp / U : 0;       // full batches of U rows
+        if (nb > 0) load(dA, xA, yA, off);
+        for (int b = 0; b < nb; b += 2) {
+            if (b + 1 < nb) load(dB, xB, yB, off + (int64_t)(b + 1) * U * step);
+            sum(dA, xA, yA);
+            if (b + 1 < nb) {
+                if (b + 2 < nb) load(dA, xA, yA, off + (int64_t)(b + 2) * U * step);
+                sum(dB, xB, yB);
+            }
         }
+        m += nb * U * L.rp;
+        off += (int64_t)nb * U * step;
         for (; m < m_end; m += L.rp, off += step) {
             Vec<T> dv = vload<T>(dy + off), xv = vload<T>(x + off), yv;
             if (ACT) yv = vload<T>(y + off);
