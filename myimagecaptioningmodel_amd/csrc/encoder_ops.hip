@@ -3,6 +3,7 @@
 // [M = B*H*W][C]; every global access is a 16-byte chunk (8 bf16 / 4 f32) of consecutive
 // channels, so a 64-lane wave touches 1 KiB of contiguous memory per instruction.
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------ elementwise glue
 template <typename T>
@@ -452,9 +453,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
                 if (wo >= Wo) continue;
                 int64_t o = (((b * Ho + ho) * Wo + wo) * cpr + cc) * VEC;
                 Vec<T> dv = vload<T>(dy + o);
+                // the VEC window indices as ONE load (they were VEC byte loads per tap)
+                typedef typename std::conditional<VEC == 8, uint64_t, uint32_t>::type IdxT;
+                static_assert(sizeof(IdxT) == VEC, "one index byte per vector element");
+                const IdxT iv = *reinterpret_cast<const IdxT*>(idx + o);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v)
-                    if (idx[o + v] == r * 3 + q) acc[v] += dv.get(v);
+                    if ((int)((iv >> (8 * v)) & 0xff) == r * 3 + q) acc[v] += dv.get(v);
             }
         }
         Vec<T> ov;
