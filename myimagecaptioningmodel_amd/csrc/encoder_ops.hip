@@ -429,44 +429,45 @@ extern "C" int capmi_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int 
     CAPMI_LAUNCH_CHECK("capmi_maxpool3x3s2_fwd");
     return 0;
 }
+// one workgroup row per input row (b, hi): no 64-bit divisions per element (the flat-index form spent more
+// instructions on five of them than on the pooling itself)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* dx, int B, int Hi, int Wi, int cpr, int Ho, int Wo) {
     constexpr int VEC = Vec<T>::N;
-    const int64_t nchunks = (int64_t)B * Hi * Wi * cpr;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nchunks; e += (int64_t)gridDim.x * 256) {
-        int cc = (int)(e % cpr);
-        int64_t m = e / cpr;
-        int wi = (int)(m % Wi), hi = (int)((m / Wi) % Hi);
-        int64_t b = m / ((int64_t)Wi * Hi);
-        float acc[VEC];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= Wi * cpr) return;
+    const int wi = t / cpr, cc = t - wi * cpr;
+    const int b = blockIdx.y / Hi, hi = blockIdx.y - b * Hi;
+    float acc[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-        for (int r = 0; r < 3; ++r) {
-            int hn = hi + 1 - r;
-            if (hn < 0 || (hn & 1)) continue;
-            int ho = hn >> 1;
-            if (ho >= Ho) continue;
-            for (int q = 0; q < 3; ++q) {
-                int wn = wi + 1 - q;
-                if (wn < 0 || (wn & 1)) continue;
-                int wo = wn >> 1;
-                if (wo >= Wo) continue;
-                int64_t o = (((b * Ho + ho) * Wo + wo) * cpr + cc) * VEC;
-                Vec<T> dv = vload<T>(dy + o);
-                // the VEC window indices as ONE load (they were VEC byte loads per tap)
-                typedef typename std::conditional<VEC == 8, uint64_t, uint32_t>::type IdxT;
-                static_assert(sizeof(IdxT) == VEC, "one index byte per vector element");
-                const IdxT iv = *reinterpret_cast<const IdxT*>(idx + o);
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
 #pragma unroll
-                for (int v = 0; v < VEC; ++v)
-                    if ((int)((iv >> (8 * v)) & 0xff) == r * 3 + q) acc[v] += dv.get(v);
-            }
+    for (int r = 0; r < 3; ++r) {
+        const int hn = hi + 1 - r;
+        if (hn < 0 || (hn & 1)) continue;
+        const int ho = hn >> 1;
+        if (ho >= Ho) continue;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int wn = wi + 1 - q;
+            if (wn < 0 || (wn & 1)) continue;
+            const int wo = wn >> 1;
+            if (wo >= Wo) continue;
+            const int64_t o = ((((int64_t)b * Ho + ho) * Wo + wo) * cpr + cc) * VEC;
+            Vec<T> dv = vload<T>(dy + o);
+            // the VEC window indices as ONE load (they were VEC byte loads per tap)
+            typedef typename std::conditional<VEC == 8, uint64_t, uint32_t>::type IdxT;
+            static_assert(sizeof(IdxT) == VEC, "one index byte per vector element");
+            const IdxT iv = *reinterpret_cast<const IdxT*>(idx + o);
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+                if ((int)((iv >> (8 * v)) & 0xff) == r * 3 + q) acc[v] += dv.get(v);
         }
-        Vec<T> ov;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) ov.set(v, acc[v]);
-        vstore<T>(dx + e * VEC, ov);
     }
+    Vec<T> ov;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) ov.set(v, acc[v]);
+    vstore<T>(dx + (((int64_t)b * Hi + hi) * Wi * cpr + t) * VEC, ov);
 }
 extern "C" int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int Hi, int Wi, int C, int Ho, int Wo,
                                       int dtype, void* stream) {
@@ -474,8 +475,8 @@ extern "C" int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* 
     CAPMI_DISPATCH(dtype, "capmi_maxpool3x3s2_bwd", {
         CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_maxpool3x3s2_bwd: C not a multiple of the vector width");
         int cpr = C / Vec<T>::N;
-        int64_t n = (int64_t)B * Hi * Wi * cpr;
-        hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, idx, (T*)dx, B, Hi, Wi, cpr, Ho, Wo);
+        CAPMI_CHECK((int64_t)B * Hi <= 65535 && (int64_t)Wi * cpr < (1ll << 30), "capmi_maxpool3x3s2_bwd: B*Hi=%lld exceeds the grid", (long long)B * Hi);
+        hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(cdiv(Wi * cpr, 256), B * Hi), dim3(256), 0, (hipStream_t)stream, (const T*)dy, idx, (T*)dx, B, Hi, Wi, cpr, Ho, Wo);
     });
     CAPMI_LAUNCH_CHECK("capmi_maxpool3x3s2_bwd");
     return 0;
