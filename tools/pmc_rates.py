@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Per-kernel LDS bank-conflict rate and MFMA busy fraction from two rocprofv3 counter passes
+"""Per-kernel LDS bank-conflict rate (and an MFMA busy column whose normalisation over XCDs is unverified: do not quote
+it) from two rocprofv3 counter passes
 (--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE ; --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; kernel trace only).
 usage: python tools/pmc_rates.py <lds_dir> <mfma_dir> <out.txt>"""
 import collections
