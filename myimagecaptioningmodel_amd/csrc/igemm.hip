@@ -1546,9 +1546,9 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(WGradArgs a) {
     tn_epilogue<BNO, BKO, TN_, TK_>(a, acc, n0, k0, split, wn, wk, fr, fg);
 }
 
-// LDS-DMA form of the weight-gradient kernel (bf16, 128 x 128 output tile, 32 reduction rows per stage,
-// 3-stage ring, no staging registers): the kernel is bound by bytes in flight from L2, not by MFMA or
-// LDS.  A stage holds dY [32][128] and X(im2col) [32][128] as unpadded 256-byte rows; a DMA wave
+// LDS-DMA form of the weight-gradient kernel (bf16, 128 x 128 output tile, 64 reduction rows per stage,
+// 2-stage ring, no staging registers): the kernel runs at ~1.5x its DMA staging time (tools/tn_ablate.hip), not
+// bound by MFMA or LDS.  A stage holds dY [64][128] and X(im2col) [64][128] as unpadded 256-byte rows; a DMA wave
 // instruction fills 4 rows.  ds_read_b64_tr_b16 touches 16 rows x 32 B per instruction, so the 16-byte
 // chunk c of row r sits at position c ^ f(r), f(r) = (r & 3) << 1 | ((r >> 3) & 1) << 3 (applied on the
 // SOURCE address of the DMA).  The instruction is served in two 32-lane halves, each 8 rows x 32 B (rows 0-3 and 8-11
