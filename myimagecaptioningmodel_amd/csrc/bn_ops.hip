@@ -494,7 +494,7 @@ __global__ __launch_bounds__(16 * LANES) void bn_bwd_reduce_final_kernel(const f
     }
 }
 static void launch_bwd_reduce_final(const float* ws, int nparts, int C, float* red, hipStream_t st) {
-    if (nparts > 512) hipLaunchKernelGGL(bn_bwd_reduce_final_kernel<64>, dim3(cdiv(2 * C, 16)), dim3(1024), 0, st, ws, nparts, 2 * C, red);
+    if (nparts >= 128) hipLaunchKernelGGL(bn_bwd_reduce_final_kernel<64>, dim3(cdiv(2 * C, 16)), dim3(1024), 0, st, ws, nparts, 2 * C, red);
     else hipLaunchKernelGGL(bn_bwd_reduce_final_kernel<16>, dim3(cdiv(2 * C, 16)), dim3(256), 0, st, ws, nparts, 2 * C, red);
 }
 /* Second stage alone: red[0..C) += sum_p ws[p][0][c], red[C..2C) += sum_p ws[p][1][c] -- for partial sums
