@@ -76,40 +76,54 @@ extern "C" int capmi_bn_stats(const void* x, int M, int C, float* ws, int dtype,
 }
 
 // ------------------------------------------------------------------ finalize (Chan merge, f64)
-// Merge of parts [p0, p1) for 64 channels per workgroup: 4 thread groups stride over the parts.
+// Merge of parts [p0, p1) for 64 channels per workgroup: 4 thread groups stride over the parts.  ONE pass: every thread
+// folds its parts with Chan's update in f64 (loads in batches of four, independent of the arithmetic), the four
+// partial results meet in LDS and are folded in a fixed order.  (The first form took two passes -- weighted mean,
+// then M2 around it -- i.e. twice the dependent load rounds in kernels that are nothing but latency.)
+__device__ __forceinline__ void chan_fold(double& n, double& mean, double& m2, double nb, double mb, double qb) {
+    if (nb <= 0.0) return;
+    const double tot = n + nb, d = mb - mean;
+    mean += d * (nb / tot);
+    m2 += qb + d * d * (n * nb / tot);
+    n = tot;
+}
 __device__ __forceinline__ void merge_parts(const float* __restrict__ ws, int part_rows, int M, int C, int c, int p0, int p1,
                                             double (*red)[64], double* mean_out, double* m2_out) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    double s = 0.0, cnt = 0.0;
-    if (c < C)
-        for (int p = p0 + ty; p < p1; p += 4) {
-            int n = min(part_rows, M - p * part_rows);
-            s += (double)n * (double)ws[((int64_t)p * C + c) * 2];
-            cnt += n;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    if (c < C) {
+        int p = p0 + ty;
+        for (; p + 12 < p1; p += 16) {
+            float mu[4], q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* w = ws + ((int64_t)(p + 4 * u) * C + c) * 2;
+                mu[u] = w[0];
+                q[u] = w[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) chan_fold(n, mean, m2, (double)min(part_rows, M - (p + 4 * u) * part_rows), (double)mu[u], (double)q[u]);
         }
-    red[ty][tx] = s;
-    red[4 + ty][tx] = cnt;
-    __syncthreads();
-    const double ntot = red[4][tx] + red[5][tx] + red[6][tx] + red[7][tx];
-    const double mean = (red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]) / (ntot > 0 ? ntot : 1.0);
-    __syncthreads();
-    double m2 = 0.0;
-    if (c < C)
-        for (int p = p0 + ty; p < p1; p += 4) {
-            int n = min(part_rows, M - p * part_rows);
+        for (; p < p1; p += 4) {
             const float* w = ws + ((int64_t)p * C + c) * 2;
-            double d = (double)w[0] - mean;
-            m2 += (double)w[1] + (double)n * d * d;
+            chan_fold(n, mean, m2, (double)min(part_rows, M - p * part_rows), (double)w[0], (double)w[1]);
         }
-    red[ty][tx] = m2;
+    }
+    __syncthreads();                 // a second call may follow a first one's reads of red
+    red[ty][tx] = mean;
+    red[4 + ty][tx] = m2;
+    red[8 + ty][tx] = n;
     __syncthreads();
-    *mean_out = mean;
-    *m2_out = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
+    double tn = 0.0, tmean = 0.0, tm2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) chan_fold(tn, tmean, tm2, red[8 + g][tx], red[g][tx], red[4 + g][tx]);
+    *mean_out = tmean;
+    *m2_out = tm2;
 }
 
 // level 1 (only when there are many parts): groups of k parts -> one merged part each
 __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__ ws, int part_rows, int M, int C, int k, float* out) {
-    __shared__ double red[8][64];
+    __shared__ double red[12][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int nparts = (M + part_rows - 1) / part_rows;
     const int p0 = blockIdx.y * k, p1 = min(nparts, p0 + k);
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int part_rows, int M, int C, const float* scale,
                                                           float* run_mean, float* run_var, float momentum, float eps,
                                                           float* saved_mean, float* saved_invstd, float* coef_a, int update_running) {
-    __shared__ double red[8][64];
+    __shared__ double red[12][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int nparts = (M + part_rows - 1) / part_rows;
     double mean, m2;
