@@ -142,17 +142,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __shared__ double red[12][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int nparts = (M + part_rows - 1) / part_rows;
+    // the per-channel scalars are fetched before the merge, not after it (one memory latency less in a kernel that is
+    // nothing but latency)
+    const bool writer = (threadIdx.x >> 6) == 0 && c < C;
+    const float sc = writer ? scale[c] : 0.f;
+    const float rm = writer && update_running ? run_mean[c] : 0.f, rv = writer && update_running ? run_var[c] : 0.f;
     double mean, m2;
     merge_parts(ws, part_rows, M, C, c, 0, nparts, red, &mean, &m2);
-    if ((threadIdx.x >> 6) != 0 || c >= C) return;
+    if (!writer) return;
     const double var = m2 / (double)M;      // biased
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     saved_mean[c] = (float)mean;
     saved_invstd[c] = invstd;
-    coef_a[c] = scale[c] * invstd;
+    coef_a[c] = sc * invstd;
     if (update_running) {
-        run_mean[c] = run_mean[c] * momentum + (float)mean * (1.f - momentum);
-        run_var[c] = run_var[c] * momentum + (float)var * (1.f - momentum);
+        run_mean[c] = rm * momentum + (float)mean * (1.f - momentum);
+        run_var[c] = rv * momentum + (float)var * (1.f - momentum);
     }
 }
 
@@ -487,6 +492,7 @@ __global__ __launch_bounds__(16 * LANES) void bn_bwd_reduce_final_kernel(const f
     __shared__ float s[LANES][17];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int j = blockIdx.x * 16 + tx;
+    const float before = (ty == 0 && j < n2c) ? red[j] : 0.f;      // fetched now, added at the end: off the dependent chain
     float acc = 0.f;
     if (j < n2c) {
         int b = ty;
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(16 * LANES) void bn_bwd_reduce_final_kernel(const f
         float tot = 0.f;
 #pragma unroll
         for (int r = 0; r < LANES; ++r) tot += s[r][tx];
-        red[j] += tot;
+        red[j] = before + tot;
     }
 }
 static void launch_bwd_reduce_final(const float* ws, int nparts, int C, float* red, hipStream_t st) {
