@@ -586,15 +586,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     const int cc = threadIdx.x % L.cpc, rr = threadIdx.x / L.cpc;
     const int chunk = blockIdx.y * L.cpc + cc;
     if (rr >= L.rp || chunk * VEC >= C) return;
+    // raw per-channel scalars now, the constants formed from them only after the first batch of row loads is in flight:
+    // formed here, the row loads would wait one memory latency for them at the start of every workgroup
     float k1[VEC], c2[VEC], m0[VEC], mu[VEC];
+    float is_[VEC], sc_[VEC], r0_[VEC], r1_[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         const int c = chunk * VEC + v;
-        const float is = invstd[c], s = scale[c];
+        is_[v] = invstd[c];
+        sc_[v] = scale[c];
         mu[v] = mean[c];
-        k1[v] = s * is;
-        c2[v] = is * red[C + c] * inv_m;
-        m0[v] = red[c] * inv_m;
+        r0_[v] = red[c];
+        r1_[v] = red[C + c];
     }
     const int m_begin = blockIdx.x * L.rows_per_block;
     const int m_end = min(M, m_begin + L.rows_per_block);
@@ -615,17 +618,34 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     };
     int m = m_begin + rr;
     int64_t off = (int64_t)m * C + (int64_t)chunk * VEC;
-    for (; m + (U - 1) * L.rp < m_end; m += U * L.rp, off += U * step) {
-        Vec<T> dv[U], xv[U], yv[U], dxo[U], dro[U];
+    Vec<T> dv[U], xv[U], yv[U], dxo[U], dro[U];
+    auto load = [&](int64_t o0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t o = off + u * step;
+            const int64_t o = o0 + u * step;
             dv[u] = vload<T>(dy + o);
             xv[u] = vload<T>(x + o);
             if (ACT) yv[u] = vload<T>(y + o);
             if (DXACC) dxo[u] = vload<T>(dx + o);
             if (DRES == 2) dro[u] = vload<T>(dres + o);
         }
+    };
+    const bool first = m + (U - 1) * L.rp < m_end;
+    if (first) load(off);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        k1[v] = sc_[v] * is_[v];
+        c2[v] = is_[v] * r1_[v] * inv_m;
+        m0[v] = r0_[v] * inv_m;
+    }
+    if (first) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) one(off + u * step, dv[u], xv[u], yv[u], dxo[u], dro[u]);
+        m += U * L.rp;
+        off += U * step;
+    }
+    for (; m + (U - 1) * L.rp < m_end; m += U * L.rp, off += U * step) {
+        load(off);
 #pragma unroll
         for (int u = 0; u < U; ++u) one(off + u * step, dv[u], xv[u], yv[u], dxo[u], dro[u]);
     }
