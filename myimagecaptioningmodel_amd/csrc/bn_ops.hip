@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
             xv[u] = vload<T>(x + off + u * step);
             if (RES) rv[u] = vload<T>(res + off + u * step);
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep the batch: the scheduler otherwise sinks every load to its use (one in flight)
 #pragma unroll
         for (int u = 0; u < U; ++u) vstore<T>(y + off + u * step, one(xv[u], rv[u]));
     }
@@ -629,6 +630,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             if (DXACC) dxo[u] = vload<T>(dx + o);
             if (DRES == 2) dro[u] = vload<T>(dres + o);
         }
+        __builtin_amdgcn_sched_barrier(0);      // keep the batch: the scheduler otherwise sinks every load to its use
     };
     const bool first = m + (U - 1) * L.rp < m_end;
     if (first) load(off);
