@@ -24,6 +24,11 @@ if ROOT not in sys.path:
 WORKLOAD = dict(encoder='resnet50', image_size=224, hidden=512, embed=512, vocab=10000, sentence_length=20,
                 infer_max_length=20, attention='slots', dtype='bf16', learning_rate=5e-5, encoder_trainable=True)
 PER_GPU_BATCH = 64
+# BASELINE configs[3] (a parity / stress case, not the bench line): ResNet-101 + 2-layer 1024-d LSTM decoder, 384x384,
+# seq_len 30, vocab 20k, 64 images per GPU (512 over 8).  E = H = 1024 and Ti = L are this build's reading of the
+# unspecified sizes (SURVEY.md section 8, table of configs)
+WORKLOAD_CFG3 = dict(encoder='resnet101', image_size=384, hidden=1024, embed=1024, vocab=20000, sentence_length=30,
+                     infer_max_length=30, attention='slots', dtype='bf16', learning_rate=5e-5, encoder_trainable=True, rnn_layer=2)
 
 
 def synthetic_batch(B, cfg, seed):

@@ -316,6 +316,44 @@ int capmi_weight_dgrad_form(const float* w, void* wt, int N, int kh, int kw, int
 int capmi_weight_dgrad_form_batched(const float* flat, void* shadow, const void* jobs, int njobs, int dtype, void* stream);
 int capmi_fill_f32(float* p, float value, int64_t n, void* stream);
 
+/* Gradient all-reduce of the data-parallel step.  Replaces the implicit NCCL all-reduce inside
+ * `fluid.ParallelExecutor(use_cuda=True, loss_name='loss', ...)` (IC/train.py:121-124, ReduceStrategy.AllReduce:
+ * per-parameter gradients SUMMED over the devices; the 1/N of GradientScaleStrategy.CoeffNumDevice is the
+ * grad_scale of capmi_adam).  One communicator per process (one process per GPU), RCCL over xGMI:
+ *   rank 0 calls capmi_comm_unique_id and hands the CAPMI_COMM_ID_BYTES bytes to every rank by any host channel
+ *   (the Python host uses torch.distributed's store); every rank then calls capmi_comm_init on its current device.
+ * capmi_allreduce_bucket: in-place f32 sum of buf[0..n) -- a contiguous bucket of the flat gradient buffer -- enqueued
+ * on `stream`; like every entry point it only enqueues.  The library uses the librccl already mapped into the process
+ * (the one behind torch.distributed's "nccl" backend), never a second copy. */
+#define CAPMI_COMM_ID_BYTES 128
+int capmi_comm_unique_id(void* id_out);
+int capmi_comm_init(void** comm, int nranks, int rank, const void* id);
+int capmi_comm_destroy(void* comm);
+int capmi_allreduce_bucket(void* comm, float* buf, int64_t n, void* stream);
+
+/* Launch plans.  A train step is a fixed sequence of ~650 of the entry points above on a few HIP streams ("lanes":
+ * 0 = the dependency chain, 1 = weight gradients and other off-chain work, 2 = communication + optimizer).  The host
+ * packs it once into a table of capmi_launch rows and replays it with ONE call per step -- the role
+ * `train_exe.run(feed, fetch_list)` (IC/train.py:139) plays over Paddle's op list.
+ *   kind CAPMI_PLAN_LAUNCH: entry `entry` (index into capmi_plan_entry_name) with `nargs` argument slots -- the entry
+ *     point's arguments in order WITHOUT its trailing stream, 8 bytes each: pointers (device pointers, or host pointers
+ *     to capmi_conv_geom / capmi_igemm_nt_call that the caller keeps alive), integers (two's complement), floats (IEEE
+ *     bits in the low 4 bytes) -- enqueued on streams[lane];
+ *   kind CAPMI_PLAN_RECORD / CAPMI_PLAN_WAIT: args[0] = an event of capmi_event_create, recorded on / awaited by
+ *     streams[lane].
+ * Returns 0, or the failing row's error (capmi_last_error names the row).  The host may patch argument slots between
+ * runs (the per-step Adam step size). */
+enum { CAPMI_PLAN_LAUNCH = 0, CAPMI_PLAN_RECORD = 1, CAPMI_PLAN_WAIT = 2 };
+#define CAPMI_PLAN_MAX_ARGS 24
+typedef struct {
+    int32_t kind, lane, entry, nargs;
+    uint64_t args[CAPMI_PLAN_MAX_ARGS];
+} capmi_launch;
+int capmi_plan_entry_count(void);
+const char* capmi_plan_entry_name(int i);
+int capmi_plan_entry_nargs(int i);
+int capmi_plan_run(const capmi_launch* table, int n, void* const* streams, int nstreams);
+
 #ifdef __cplusplus
 }
 #endif

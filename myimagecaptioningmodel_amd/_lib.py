@@ -88,6 +88,7 @@ SIGNATURES = {
     'capmi_weight_dgrad_form': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'capmi_weight_dgrad_form_batched': [_p, _p, _p, _i, _i, _p],
     'capmi_fill_f32': [_p, _f, _l, _p],
+    'capmi_allreduce_bucket': [_p, _p, _l, _p],
 }
 
 
@@ -112,6 +113,26 @@ SYNC = {
     'capmi_stream_wait_event': [_p, _p],
     'capmi_stream_create': [_p, _i],     # void** stream, priority
 }
+
+# communicator management (no stream): name -> argument ctypes
+COMM = {
+    'capmi_comm_unique_id': [_p],
+    'capmi_comm_init': [_p, _i, _i, _p],      # void** comm, nranks, rank, id
+    'capmi_comm_destroy': [_p],
+}
+COMM_ID_BYTES = 128
+
+PLAN_MAX_ARGS = 24
+PLAN_LAUNCH, PLAN_RECORD, PLAN_WAIT = 0, 1, 2
+
+
+class Launch(ctypes.Structure):
+    """capmi_launch (include/capmi.h): one row of a packed launch table."""
+    _fields_ = [('kind', ctypes.c_int32), ('lane', ctypes.c_int32), ('entry', ctypes.c_int32), ('nargs', ctypes.c_int32),
+                ('args', ctypes.c_uint64 * PLAN_MAX_ARGS)]
+
+
+PLAN_ENTRIES = {}       # entry-point name -> index in the library's plan entry table (filled by lib())
 
 _lib = None
 
@@ -140,8 +161,24 @@ def lib():
             fn = getattr(L, name)
             fn.argtypes = args
             fn.restype = ctypes.c_int
+        for name, args in COMM.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = ctypes.c_int
         L.capmi_igemm_tn_ws_bytes.argtypes = [_i, _i, _i, _i]
         L.capmi_igemm_tn_ws_bytes.restype = ctypes.c_longlong
+        L.capmi_plan_entry_count.restype = ctypes.c_int
+        L.capmi_plan_entry_name.argtypes = [_i]
+        L.capmi_plan_entry_name.restype = ctypes.c_char_p
+        L.capmi_plan_entry_nargs.argtypes = [_i]
+        L.capmi_plan_entry_nargs.restype = ctypes.c_int
+        L.capmi_plan_run.argtypes = [ctypes.POINTER(Launch), _i, ctypes.POINTER(ctypes.c_void_p), _i]
+        L.capmi_plan_run.restype = ctypes.c_int
+        for i in range(L.capmi_plan_entry_count()):
+            name = L.capmi_plan_entry_name(i).decode()
+            if L.capmi_plan_entry_nargs(i) != len(SIGNATURES[name]) - 1:
+                raise CapmiError('%s: the plan entry table and the binding disagree on its arity' % name)
+            PLAN_ENTRIES[name] = i
         _lib = L
     return _lib
 
@@ -161,47 +198,70 @@ WGRAD_WS_BYTES = 32 << 20      # >= any capmi_igemm_tn_ws_bytes() result (partia
 _wgrad_ws = {}
 
 
-def wgrad_workspace(device):
-    """One shared f32 scratch buffer per device for the weight-gradient partial slabs (launches on
-    one stream run in order, so they can share it)."""
+def wgrad_workspace(device, lane=1):
+    """One f32 scratch buffer per (device, lane) for the weight-gradient partial slabs: launches on one stream run
+    in order and can share it; launches on different lanes never do."""
     import torch
-    key = str(device)
+    key = (str(device), int(lane))
     if key not in _wgrad_ws:
         _wgrad_ws[key] = torch.zeros(WGRAD_WS_BYTES // 4, dtype=torch.float32, device=device)
     return _wgrad_ws[key]
 
 
 class _SideCall:
-    """A launch that may run on the plan's side stream (lane 1); calling it is calling the entry point."""
-    lane = 1
+    """A launch that may run on another stream than the main lane; calling it is calling the entry point."""
 
-    def __init__(self, fn):
-        self.fn = fn
+    def __init__(self, fn, lane):
+        self.fn, self.lane = fn, lane
 
     def __call__(self, *args):
         return self.fn(*args)
 
 
+def _float_bits(x):
+    import struct
+    return struct.unpack('<I', struct.pack('<f', float(x)))[0]
+
+
+def _slot(value, ctype):
+    """One argument as the 8-byte slot capmi_plan_run expects; (bits, patch source or None)."""
+    if ctype is _f:
+        if isinstance(value, ctypes.c_float):          # re-read before every run (the per-step Adam step size)
+            return _float_bits(value.value), value
+        return _float_bits(value), None
+    if value is None:
+        return 0, None
+    if isinstance(value, (ctypes.Structure, ctypes.Array)):
+        return ctypes.addressof(value), None            # host struct kept alive by Plan._keep
+    if isinstance(value, ctypes.c_void_p):
+        return value.value or 0, None
+    return int(value) & 0xFFFFFFFFFFFFFFFF, None
+
+
 class Plan:
-    """A recorded launch sequence: (function, name, args-without-stream).  `run(stream)` replays it on
-    a HIP stream; static shapes make the whole sequence capturable in a hipGraph.
+    """A recorded launch sequence: (function, name, args-without-stream).  `run(stream)` replays it through
+    capmi_plan_run -- the whole sequence in ONE foreign call -- on up to three HIP streams; static shapes make a
+    single-lane sequence capturable in a hipGraph.
 
-    Lanes: a call added with lane=1 may run on a side stream, ordered against the main lane only by
-    the `record(key, lane)` / `wait(key, lane)` entries around it.  The recorded order is always a valid
-    sequential order, so replaying everything on one stream (side=False, or any consumer that just
-    iterates `calls`) gives the same results."""
+    Lanes: a call added with lane=1 (weight gradients and other work off the dependency chain) or lane=2
+    (communication + optimizer of the data-parallel step) may run on its own stream, ordered against the others only by
+    the `record(key, lane)` / `wait(key, lane)` entries around it.  The recorded order is always a valid sequential
+    order, so replaying everything on one stream (side=False, or any consumer that just iterates `calls`) gives the
+    same results.  CAPMI_PY_PLAN=1 walks the table from Python, one foreign call per launch (the round-1 host path;
+    kept for the equivalence test and for debugging a single launch)."""
 
-    _side = {}          # device index -> torch side stream
+    _side = {}          # device index -> {'streams': {lane: stream}, 'fork': event, 'join': {lane: event}}
 
     def __init__(self):
         self.calls = []
         self._keep = []      # keeps ConvGeom structs / tensors alive
         self.has_lanes = False
+        self._compiled = {}
 
     def add(self, name, *args, lane=0):
         fn = getattr(lib(), name)
         if lane:
-            fn = _SideCall(fn)
+            fn = _SideCall(fn, lane)
             self.has_lanes = True
         self.calls.append((fn, name, args))
         self._keep.append(args)
@@ -226,52 +286,132 @@ class Plan:
         """The kernel launches only: (fn, name, args), synchronisation entries skipped."""
         return [c for c in self.calls if c[0] is not None]
 
+    # ------------------------------------------------------------------ lanes of a device
+    @staticmethod
+    def _lane_streams(lanes_needed):
+        import torch
+        L = lib()
+        dev = torch.cuda.current_device()
+        side = Plan._side.setdefault(dev, dict(streams={}, fork=None, join={}))
+        if side['fork'] is None:
+            ev = ctypes.c_void_p()
+            if L.capmi_event_create(ctypes.byref(ev)):
+                raise CapmiError('lanes: %s' % last_error())
+            side['fork'] = ev
+        for lane in lanes_needed:
+            if lane and lane not in side['streams']:
+                # lane 1 (weight gradients): lowest priority, it fills the main lane's gaps; lane 2 (all-reduce +
+                # optimizer): CAPMI_COMM_PRIORITY (default 0)
+                s, ev = ctypes.c_void_p(), ctypes.c_void_p()
+                prio = int(os.environ.get('CAPMI_SIDE_PRIORITY', '-1')) if lane == 1 else int(os.environ.get('CAPMI_COMM_PRIORITY', '0'))
+                if L.capmi_stream_create(ctypes.byref(s), prio) or L.capmi_event_create(ctypes.byref(ev)):
+                    raise CapmiError('lane %d: %s' % (lane, last_error()))
+                side['streams'][lane], side['join'][lane] = s, ev
+        return side
+
+    def _compile(self, lanes):
+        """The packed capmi_launch table of this plan: (rows, n, patches, lanes used).  lanes=False drops the
+        synchronisation entries and maps every call to lane 0."""
+        L = lib()
+        rows, patches, events, used = [], [], {}, {0}
+        side = Plan._lane_streams({getattr(fn, 'lane', 0) for fn, _, _ in self.calls if fn is not None}) if lanes else None
+
+        def sync_row(kind, ev, lane):
+            r = Launch()
+            r.kind, r.lane, r.entry, r.nargs = kind, lane, -1, 1
+            r.args[0] = ev.value
+            return r
+        body = []
+        for fn, name, args in self.calls:
+            if fn is None:
+                key, lane = args
+                if not lanes:
+                    continue
+                if name == 'record':
+                    ev = ctypes.c_void_p()
+                    if L.capmi_event_create(ctypes.byref(ev)) != 0:
+                        raise CapmiError('capmi_event_create: %s' % last_error())
+                    events[key] = ev
+                    body.append(sync_row(PLAN_RECORD, ev, lane))
+                elif key in events:             # waits on keys recorded in an earlier run are dropped
+                    body.append(sync_row(PLAN_WAIT, events[key], lane))
+                used.add(lane)
+                continue
+            types = SIGNATURES[name]
+            if len(args) != len(types) - 1:
+                raise CapmiError('%s: %d arguments recorded, the entry point takes %d (+ stream)' % (name, len(args), len(types) - 1))
+            r = Launch()
+            r.kind, r.entry, r.nargs = PLAN_LAUNCH, PLAN_ENTRIES[name], len(args)
+            r.lane = getattr(fn, 'lane', 0) if lanes else 0
+            used.add(r.lane)
+            for i, (a, t) in enumerate(zip(args, types)):
+                r.args[i], src = _slot(a, t)
+                if src is not None:
+                    patches.append((len(body), i, src))
+            body.append(r)
+        if lanes:       # fork: every other lane starts behind the main lane's current position; join: the main lane waits for them
+            head = [sync_row(PLAN_RECORD, side['fork'], 0)] + [sync_row(PLAN_WAIT, side['fork'], l) for l in sorted(used - {0})]
+            tail = []
+            for l in sorted(used - {0}):
+                tail += [sync_row(PLAN_RECORD, side['join'][l], l), sync_row(PLAN_WAIT, side['join'][l], 0)]
+            patches = [(r + len(head), i, src) for r, i, src in patches]
+            body = head + body + tail
+        table = (Launch * max(1, len(body)))(*body)
+        return dict(table=table, n=len(body), patches=patches, events=events, used=sorted(used), side=side)
+
     def run(self, stream, side=True):
-        lanes = side and self.has_lanes and os.environ.get('CAPMI_LANES', '1') != '0'
+        lanes = bool(side and self.has_lanes and os.environ.get('CAPMI_LANES', '1') != '0')
+        if os.environ.get('CAPMI_PY_PLAN', '0') == '1':
+            return self._run_py(stream, lanes)
+        key = (lanes, len(self.calls))
+        c = self._compiled.get(key)
+        if c is None:
+            c = self._compiled[key] = self._compile(lanes)
+        for row, slot, src in c['patches']:
+            c['table'][row].args[slot] = _float_bits(src.value)
+        streams = (ctypes.c_void_p * 3)(stream, stream, stream)
+        if lanes:
+            for l, s in c['side']['streams'].items():
+                streams[l] = s.value
+        if lib().capmi_plan_run(c['table'], c['n'], streams, 3) != 0:
+            raise CapmiError('plan: %s' % last_error())
+
+    def _run_py(self, stream, lanes):
+        """The same sequence, one foreign call per launch."""
+        L = lib()
         if not lanes:
             for fn, name, args in self.calls:
                 if fn is not None and fn(*args, stream) != 0:
                     raise CapmiError('%s failed: %s' % (name, last_error()))
             return
-        import torch
-        L = lib()
-        dev = torch.cuda.current_device()
-        side = Plan._side.get(dev)
-        if side is None:            # (stream, fork event, join event): lowest priority, it fills the main lane's gaps
-            s, e0, e1 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
-            prio = int(os.environ.get('CAPMI_SIDE_PRIORITY', '-1'))
-            if L.capmi_stream_create(ctypes.byref(s), prio) or L.capmi_event_create(ctypes.byref(e0)) or L.capmi_event_create(ctypes.byref(e1)):
-                raise CapmiError('side lane: %s' % last_error())
-            side = Plan._side[dev] = (s, e0, e1)
-        s1, fork_ev, join_ev = side
-        prog = getattr(self, '_prog', None)
-        if prog is None or self._prog_key != (len(self.calls), stream, s1.value):
-            # compiled form: ('launch', raw entry point, args + stream) / ('record' | 'wait', event, stream); waits on
-            # keys recorded in an earlier run are dropped; stream pointers are baked in (the key checks them)
-            prog, events = [], {}
-            ptrs = (stream, s1)
-            for fn, name, args in self.calls:
-                if fn is None:
-                    key, lane = args
-                    if name == 'record':
-                        ev = ctypes.c_void_p()
-                        if L.capmi_event_create(ctypes.byref(ev)) != 0:
-                            raise CapmiError('capmi_event_create: %s' % last_error())
-                        events[key] = ev
-                        prog.append((1, L.capmi_event_record, (ev, ptrs[lane])))
-                    elif key in events:
-                        prog.append((2, L.capmi_stream_wait_event, (ptrs[lane], events[key])))
+        c = self._compiled.get(('py', len(self.calls)))
+        if c is None:
+            c = self._compiled[('py', len(self.calls))] = self._compile(True)
+        ptrs = {0: stream}
+        ptrs.update({l: s.value for l, s in c['side']['streams'].items()})
+        others = [l for l in c['used'] if l]
+        L.capmi_event_record(c['side']['fork'], stream)
+        for l in others:
+            L.capmi_stream_wait_event(ptrs[l], c['side']['fork'])
+        events = c['events']
+        seen = set()
+        for fn, name, args in self.calls:
+            if fn is None:
+                key, lane = args
+                if name == 'record':
+                    seen.add(key)
+                    rc = L.capmi_event_record(events[key], ptrs[lane])
+                elif key in seen:
+                    rc = L.capmi_stream_wait_event(ptrs[lane], events[key])
                 else:
-                    lane = getattr(fn, 'lane', 0)
-                    prog.append((0, getattr(fn, 'fn', fn), tuple(args) + (ptrs[lane],)))
-            self._prog, self._prog_key = prog, (len(self.calls), stream, s1.value)
-        L.capmi_event_record(fork_ev, stream)             # fork
-        L.capmi_stream_wait_event(s1, fork_ev)
-        for kind, fn, args in prog:
-            if fn(*args) != 0:
-                raise CapmiError('launch failed: %s' % last_error())
-        L.capmi_event_record(join_ev, s1)                 # join
-        L.capmi_stream_wait_event(stream, join_ev)
+                    rc = 0
+            else:
+                rc = getattr(fn, 'fn', fn)(*args, ptrs[getattr(fn, 'lane', 0)])
+            if rc != 0:
+                raise CapmiError('%s failed: %s' % (name, last_error()))
+        for l in others:
+            L.capmi_event_record(c['side']['join'][l], ptrs[l])
+            L.capmi_stream_wait_event(stream, c['side']['join'][l])
 
     def __len__(self):
         return len(self.calls)

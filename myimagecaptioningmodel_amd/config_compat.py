@@ -30,6 +30,7 @@ def from_reference_config(config, **overrides):
         start_idx=int(data['start_idx']), stop_idx=int(data['stop_idx']), padding_idx=int(data['padding_idx']),
         encoder_trainable=bool(enc['encoder_trainable']),
         attention='singleton',                       # reference-faithful quirk Q1
+        rnn_layer=1,                                 # model_adaAttention_aic.py:174 builds Decoder(..., rnn_layer=1)
         dtype='f32',                                 # the reference computes in fp32 throughout
         learning_rate=float(train['learning_rate']), lr_decay_strategy=train['lr_decay_strategy'],
         decay_epoch=train['decay_epoch'], warmup_epoch=train['warmup_epoch'], max_epoch=int(train['max_epoch']),
@@ -44,7 +45,7 @@ def default_cfg(**overrides):
     """Repo-default hyper-parameters (config.py:15,22-24,31-43,50,55-60) without needing the module."""
     cfg = dict(encoder='mobilenetv2', image_size=224, hidden=1024, embed=256, vocab=12295, sentence_length=35,
                infer_max_length=35, start_idx=2, stop_idx=3, padding_idx=0, encoder_trainable=True,
-               attention='singleton', dtype='f32', learning_rate=5e-5, lr_decay_strategy=None, decay_epoch=0,
+               attention='singleton', rnn_layer=1, dtype='f32', learning_rate=5e-5, lr_decay_strategy=None, decay_epoch=0,
                warmup_epoch=3, max_epoch=10, gradient_clip=False, batch_size=128, sample_count=944996, seed=None)
     cfg.update(overrides)
     return cfg

@@ -11,6 +11,11 @@ projection except h_{t-1}.W_h runs ONCE over all T steps as an M = T*B row GEMM;
 time-major (m = t*B + b) so a timestep is a contiguous row block.  Per step only the
 [B,H]x[H,4H] recurrent GEMM (accumulated onto the precomputed input gates in its epilogue)
 and the pointwise cell remain.  BPTT mirrors it.
+
+`rnn_layer` > 1 (build-defined stacked decoder of BASELINE configs[3]; the reference stores the argument and never
+reads it, :42,46,174): layer l >= 1 is another lstm_unit (`lstm_w_l<l>` [H+H, 4H], `lstm_b_l<l>`) fed with the new
+hidden state of layer l-1; sentinel, attention and the output head read the TOP layer.  In train mode the layers run
+one after another over all T steps: layer l's input gates are ONE M = T*B row GEMM over layer l-1's hidden states.
 """
 import os
 
@@ -42,6 +47,7 @@ class DecoderRunner:
         self.code, self.tdt = dtype_code, torch_dtype
         self.slots = 1 if slots else 0
         self.pad = cfg['padding_idx']
+        self.L = int(cfg.get('rnn_layer', 1))
         dev = store.device
         B, K, T, C, H, E, M = self.B, self.K, self.T, self.C, self.H, self.E, T * B
         z = lambda shape, dt=None: torch.zeros(shape, dtype=dt or self.tdt, device=dev)
@@ -52,8 +58,11 @@ class DecoderRunner:
         self.Vt = z((B * K, H))
         self.Ve = z((B * K, H)) if slots else None
         self.X = z((M, E + H))
-        self.G = z((M, 4 * H))
-        self.Hbuf, self.Cbuf = z(((T + 1) * B, H)), z(((T + 1) * B, H))
+        # per LSTM layer: gate pre-activations and (T+1) row blocks of h / c (block 0 = the zero state, :63)
+        self.Gs = [z((M, 4 * H)) for _ in range(self.L)]
+        self.Hbufs = [z(((T + 1) * B, H)) for _ in range(self.L)]
+        self.Cbufs = [z(((T + 1) * B, H)) for _ in range(self.L)]
+        self.G, self.Hbuf, self.Cbuf = self.Gs[0], self.Hbufs[-1], self.Cbufs[-1]     # Hbuf / Cbuf: the TOP layer (what the loop body reads after the LSTM)
         self.SGpre, self.S, self.P = z((M, H)), z((M, H)), z((M, H))
         self.Q = z((M, H)) if slots else None
         self.SE = z((M, H)) if slots else None
@@ -71,8 +80,11 @@ class DecoderRunner:
             self.dQ = z((M, H)) if slots else None
             self.dSE = z((M, H)) if slots else None
             self.de = z((M, K + 1), f32)
-            self.dHbuf, self.dCbuf = z(((T + 1) * B, H)), z(((T + 1) * B, H))
-            self.dSGpre, self.dX, self.dG = z((M, H)), z((M, E + H)), z((M, 4 * H))
+            self.dHbufs = [z(((T + 1) * B, H)) for _ in range(self.L)]
+            self.dCbufs = [z(((T + 1) * B, H)) for _ in range(self.L)]
+            self.dGs = [z((M, 4 * H)) for _ in range(self.L)]
+            self.dHbuf, self.dCbuf, self.dG = self.dHbufs[-1], self.dCbufs[-1], self.dGs[0]
+            self.dSGpre, self.dX = z((M, H)), z((M, E + H))
             self.dg, self.dV0, self.dAmean = z((B, H)), z((B * K, H)), z((B, C))
 
     # ------------------------------------------------------------------ tiny helpers
@@ -99,14 +111,21 @@ class DecoderRunner:
     def _wgrad(self, plan, x, rows, K, dy, N, dw, ldx=None, ldy=None, lddw=None):
         """dw[N][K] += dy[rows][N]^T . x[rows][K]"""
         g = gemm_geom(rows, K, ldx)
+        lane = self._side_ready(plan)
         plan.add('capmi_igemm_tn_wgrad', x, dy, dw, g, N, N if ldy is None else ldy, K if lddw is None else lddw,
-                 _p(wgrad_workspace(self.store.device)), WGRAD_WS_BYTES, self.code, lane=self._side_ready(plan))
+                 _p(wgrad_workspace(self.store.device, lane)), WGRAD_WS_BYTES, self.code, lane=lane)
 
     def _colsum(self, plan, a, rows, N, out, lda=None):
         plan.add('capmi_colsum', a, rows, N, N if lda is None else lda, out, self.code, lane=self._side_ready(plan))
 
     def _fc(self, key):
         return FC[key] + '.w_0', FC[key] + '.b_0'
+
+    def _lstm(self, l):
+        """(weight name, bias name, input width) of LSTM layer l; kernel layout [4H][in | H], row stride in + H."""
+        if l == 0:
+            return 'lstm_w', 'lstm_b', self.E + self.H
+        return 'lstm_w_l%d' % l, 'lstm_b_l%d' % l, self.H
 
     # ------------------------------------------------------------------ shared forward pieces
     def _plan_bridge(self, plan, A, W):
@@ -167,22 +186,27 @@ class DecoderRunner:
         # x_t = [embedding(w_t) ; g]  (:84-86), all steps at once
         plan.add('capmi_embedding_fwd', _p(self.ids), _p(W('word_embedding')), _p(self.X), M, E, self.V, E + H, self.pad, code)
         plan.add('capmi_bcast_rows', _p(self.g), _p(self.X), T, B, H, E + H, E, code)
-        # input part of the gates for every step: G = X . Wx^T + lstm_b   (lstm_w kernel layout [4H][E+H | H])
-        lw = W('lstm_w')
-        ldl = E + 2 * H
-        self._gemm(plan, _p(self.X), M, E + H, _p(lw), 4 * H, _p(self.G), ldw=ldl, bias=_p(st.view('lstm_b')))
-        wh = _p(lw) + (E + H) * es
-        fused = self.fuse_lstm and os.environ.get('CAPMI_LSTM_FUSE', '1') != '0' and bool(lib().capmi_lstm_step_supported(B, H, code))   # one launch per step
-        for t in range(T):                                                                                        # :75-127
-            Gt = _p(self.G) + t * B * 4 * H * es
-            if t > 0 and fused:
-                plan.add('capmi_lstm_step_fwd', _p(self.Hbuf) + t * B * H * es, wh, ldl, Gt, _p(self.Cbuf) + t * B * H * es,
-                         _p(self.Hbuf) + (t + 1) * B * H * es, _p(self.Cbuf) + (t + 1) * B * H * es, B, H, code)
-                continue
-            if t > 0:     # h_{-1} = 0 (:63): nothing to add at t = 0
-                self._gemm(plan, _p(self.Hbuf) + t * B * H * es, B, H, wh, 4 * H, Gt, ldw=ldl, addend=Gt, ld_add=4 * H)
-            plan.add('capmi_lstm_cell_fwd', Gt, _p(self.Cbuf) + t * B * H * es, _p(self.Hbuf) + (t + 1) * B * H * es,
-                     _p(self.Cbuf) + (t + 1) * B * H * es, B, H, code)                                            # :87-88
+        # per layer: input part of the gates for every step in one GEMM (G = in . Wx^T + b; kernel layout [4H][in | H]),
+        # then the recurrence: only h_{t-1} . Wh^T and the cell are sequential
+        off1 = B * H * es
+        for l in range(self.L):
+            wn, bn, kin = self._lstm(l)
+            lw, ldl = W(wn), kin + H
+            G, Hb, Cb = self.Gs[l], self.Hbufs[l], self.Cbufs[l]
+            xin = _p(self.X) if l == 0 else _p(self.Hbufs[l - 1]) + off1
+            self._gemm(plan, xin, M, kin, _p(lw), 4 * H, _p(G), ldw=ldl, bias=_p(st.view(bn)))
+            wh = _p(lw) + kin * es
+            fused = self.fuse_lstm and os.environ.get('CAPMI_LSTM_FUSE', '1') != '0' and bool(lib().capmi_lstm_step_supported(B, H, code))   # one launch per step
+            for t in range(T):                                                                                    # :75-127
+                Gt = _p(G) + t * B * 4 * H * es
+                if t > 0 and fused:
+                    plan.add('capmi_lstm_step_fwd', _p(Hb) + t * B * H * es, wh, ldl, Gt, _p(Cb) + t * B * H * es,
+                             _p(Hb) + (t + 1) * B * H * es, _p(Cb) + (t + 1) * B * H * es, B, H, code)
+                    continue
+                if t > 0:     # h_{-1} = 0 (:63): nothing to add at t = 0
+                    self._gemm(plan, _p(Hb) + t * B * H * es, B, H, wh, 4 * H, Gt, ldw=ldl, addend=Gt, ld_add=4 * H)
+                plan.add('capmi_lstm_cell_fwd', Gt, _p(Cb) + t * B * H * es, _p(Hb) + (t + 1) * B * H * es,
+                         _p(Cb) + (t + 1) * B * H * es, B, H, code)                                                # :87-88
         off1 = B * H * es
         self._plan_post_lstm(plan, W, M, _p(self.X), _p(self.Hbuf), _p(self.Hbuf) + off1, _p(self.Cbuf) + off1)
         plan.add('capmi_softmax_xent_fwd', _p(self.logits), _p(self.tgt), _p(self.row_loss), _p(self.row_lse), M, self.V,
@@ -256,30 +280,42 @@ class DecoderRunner:
         self._gemm(plan, _p(self.dSGpre), M, H, _p(WT(w5)), E + H, _p(self.dX))
         # d h_{t-1} through fc_6 lands one row block earlier in dHbuf (block 0 = h_{-1}, unused)
         self._gemm(plan, _p(self.dSGpre), M, H, _p(WT(w6)), H, _p(self.dHbuf), addend=_p(self.dHbuf), ld_add=H)
-        # BPTT through the lstm_unit (:87-88)
-        lwT = WT('lstm_w')                       # [E+2H][4H]
-        whT = _p(lwT) + (E + H) * 4 * H * es
-        # measured at cfg 2: the fused forward step wins (10.8 us vs 15.7 + 5.2), the fused backward step (16 workgroups
-        # carrying the whole cell backward) loses to product + cell (18-29 us vs 7.9 + 6.0): forward only by default
-        fused = self.fuse_lstm and os.environ.get('CAPMI_LSTM_FUSE', '1') == '2' and bool(lib().capmi_lstm_step_supported(B, H, code))
-        for t in reversed(range(T)):
-            blk = lambda buf, i: _p(buf) + i * B * H * es
-            Gt = _p(self.G) + t * B * 4 * H * es
-            dGt = _p(self.dG) + t * B * 4 * H * es
-            if not fused or t == T - 1:
-                plan.add('capmi_lstm_cell_bwd', Gt, blk(self.Cbuf, t), blk(self.Cbuf, t + 1), blk(self.dHbuf, t + 1),
-                         blk(self.dCbuf, t + 1), dGt, blk(self.dCbuf, t) if t > 0 else None, 1, B, H, code)
-            if t > 0 and fused:
-                # dh_{t-1} += dG_t . Wh and the cell backward of step t-1 in one launch
-                plan.add('capmi_lstm_step_bwd', dGt, whT, 4 * H, blk(self.dHbuf, t), Gt - B * 4 * H * es, blk(self.Cbuf, t - 1), blk(self.Cbuf, t),
-                         blk(self.dCbuf, t), dGt - B * 4 * H * es, blk(self.dCbuf, t - 1) if t > 1 else None, 1, B, H, code)
-            elif t > 0:
-                self._gemm(plan, dGt, B, 4 * H, whT, H, blk(self.dHbuf, t), addend=blk(self.dHbuf, t), ld_add=H)
-        ldl = E + 2 * H
-        self._wgrad(plan, _p(self.X), M, E + H, _p(self.dG), 4 * H, g_('lstm_w'), lddw=ldl)
-        self._wgrad(plan, Hprev, M, H, _p(self.dG), 4 * H, g_('lstm_w') + (E + H) * 4, lddw=ldl)
-        self._colsum(plan, _p(self.dG), M, 4 * H, g_('lstm_b'))
-        self._gemm(plan, _p(self.dG), M, 4 * H, _p(lwT), E + H, _p(self.dX), addend=_p(self.dX), ld_add=E + H)
+        # BPTT through the lstm_unit layers (:87-88), top layer first.  The top layer's dHbuf / dCbuf hold what the loop
+        # body's readers left there (above); a lower layer's d h_t is the input gradient of the layer above it.
+        for l in reversed(range(self.L)):
+            wn, bn, kin = self._lstm(l)
+            lwT = WT(wn)                             # [kin + H][4H]
+            whT = _p(lwT) + kin * 4 * H * es
+            G, dG, Cb, dHb, dCb = self.Gs[l], self.dGs[l], self.Cbufs[l], self.dHbufs[l], self.dCbufs[l]
+            top = l == self.L - 1
+            # measured at cfg 2: the fused forward step wins (10.8 us vs 15.7 + 5.2), the fused backward step (16 workgroups
+            # carrying the whole cell backward) loses to product + cell (18-29 us vs 7.9 + 6.0): forward only by default
+            fused = self.fuse_lstm and os.environ.get('CAPMI_LSTM_FUSE', '1') == '2' and bool(lib().capmi_lstm_step_supported(B, H, code))
+            for t in reversed(range(T)):
+                blk = lambda buf, i: _p(buf) + i * B * H * es
+                Gt = _p(G) + t * B * 4 * H * es
+                dGt = _p(dG) + t * B * 4 * H * es
+                # incoming d c_t: the sentinel's share + step t+1's (top layer, accumulated in place); step t+1's only below it
+                dc_in = blk(dCb, t + 1) if (top or t < T - 1) else None
+                acc = 1 if top else 0
+                if not fused or t == T - 1:
+                    plan.add('capmi_lstm_cell_bwd', Gt, blk(Cb, t), blk(Cb, t + 1), blk(dHb, t + 1),
+                             dc_in, dGt, blk(dCb, t) if t > 0 else None, acc, B, H, code)
+                if t > 0 and fused:
+                    # dh_{t-1} += dG_t . Wh and the cell backward of step t-1 in one launch
+                    plan.add('capmi_lstm_step_bwd', dGt, whT, 4 * H, blk(dHb, t), Gt - B * 4 * H * es, blk(Cb, t - 1), blk(Cb, t),
+                             blk(dCb, t), dGt - B * 4 * H * es, blk(dCb, t - 1) if t > 1 else None, acc, B, H, code)
+                elif t > 0:
+                    self._gemm(plan, dGt, B, 4 * H, whT, H, blk(dHb, t), addend=blk(dHb, t), ld_add=H)
+            ldl = kin + H
+            xin = _p(self.X) if l == 0 else _p(self.Hbufs[l - 1]) + off1
+            self._wgrad(plan, xin, M, kin, _p(dG), 4 * H, g_(wn), lddw=ldl)
+            self._wgrad(plan, _p(self.Hbufs[l]), M, H, _p(dG), 4 * H, g_(wn) + kin * 4, lddw=ldl)
+            self._colsum(plan, _p(dG), M, 4 * H, g_(bn))
+            if l == 0:
+                self._gemm(plan, _p(dG), M, 4 * H, _p(lwT), kin, _p(self.dX), addend=_p(self.dX), ld_add=kin)
+            else:       # d h of layer l-1 for every step (blocks 1..T of its dHbuf): written, then its own BPTT adds into it
+                self._gemm(plan, _p(dG), M, 4 * H, _p(lwT), H, _p(self.dHbufs[l - 1]) + off1)
         # x_t = [emb ; g] (:84-86)
         if self.overlap_wgrad:
             plan.wait(('dec', 'tied projection'), 0)
@@ -318,19 +354,21 @@ class DecoderRunner:
         es = self.X.element_size()
         self._plan_bridge(plan, A, W)
         plan.add('capmi_bcast_rows', _p(self.g), _p(self.X), 1, B, H, E + H, E, code)
-        lw = W('lstm_w')
-        ldl = E + 2 * H
-        wh = _p(lw) + (E + H) * es
-        # two (h, c) row blocks used alternately: block 0 starts as the zero state (:63)
+        # per layer two (h, c) row blocks used alternately: block 0 starts as the zero state (:63)
         for t in range(Ti):
             cur, nxt = (t % 2), ((t + 1) % 2)
-            hp, cp = _p(self.Hbuf) + cur * B * H * es, _p(self.Cbuf) + cur * B * H * es
-            hn, cn = _p(self.Hbuf) + nxt * B * H * es, _p(self.Cbuf) + nxt * B * H * es
             plan.add('capmi_embedding_fwd', _p(self.ids), _p(W('word_embedding')), _p(self.X), B, E, self.V, E + H, self.pad, code)
-            self._gemm(plan, _p(self.X), B, E + H, _p(lw), 4 * H, _p(self.G), ldw=ldl, bias=_p(st.view('lstm_b')))
-            self._gemm(plan, hp, B, H, wh, 4 * H, _p(self.G), ldw=ldl, addend=_p(self.G), ld_add=4 * H)
-            plan.add('capmi_lstm_cell_fwd', _p(self.G), cp, hn, cn, B, H, code)
-            self._plan_post_lstm(plan, W, B, _p(self.X), hp, hn, cn)
+            xin = _p(self.X)
+            for l in range(self.L):
+                wn, bn, kin = self._lstm(l)
+                lw, ldl = W(wn), kin + H
+                hp, cp = _p(self.Hbufs[l]) + cur * B * H * es, _p(self.Cbufs[l]) + cur * B * H * es
+                hn, cn = _p(self.Hbufs[l]) + nxt * B * H * es, _p(self.Cbufs[l]) + nxt * B * H * es
+                self._gemm(plan, xin, B, kin, _p(lw), 4 * H, _p(self.G), ldw=ldl, bias=_p(st.view(bn)))
+                self._gemm(plan, hp, B, H, _p(lw) + kin * es, 4 * H, _p(self.G), ldw=ldl, addend=_p(self.G), ld_add=4 * H)
+                plan.add('capmi_lstm_cell_fwd', _p(self.G), cp, hn, cn, B, H, code)
+                xin = hn
+            self._plan_post_lstm(plan, W, B, _p(self.X), hp, hn, cn)       # top layer: previous h, new h, new c
             plan.add('capmi_argmax', _p(self.logits), _p(self.ids), _p(out_ids_f32) + t * 4, Ti, B, self.V, self.Vld)  # :120-123
 
     def plan_beam(self, plan, A, W, out_ids_f32, Ti, beam):
@@ -345,32 +383,37 @@ class DecoderRunner:
         R = beam * B
         dev = self.X.device
         z = lambda shape, dt: torch.zeros(shape, dtype=dt, device=dev)
-        self.beam_h = [z((R, H), self.tdt) for _ in range(2)]       # [0] = state fed to the step, [1] = state it produces
-        self.beam_c = [z((R, H), self.tdt) for _ in range(2)]
+        # per layer: [0] = state fed to the step, [1] = state it produces
+        self.beam_h = [[z((R, H), self.tdt) for _ in range(2)] for _ in range(self.L)]
+        self.beam_c = [[z((R, H), self.tdt) for _ in range(2)] for _ in range(self.L)]
         self.beam_score = [z((beam, B), torch.float32) for _ in range(2)]
         self.beam_cand_val, self.beam_cand_idx = z((R, beam), torch.float32), z((R, beam), torch.int32)
         self.beam_lse, self.beam_rows = z((R,), torch.float32), z((R,), torch.int32)
         self.beam_parents, self.beam_tokens = z((Ti, beam, B), torch.int32), z((Ti, beam, B), torch.int32)
         self._plan_bridge(plan, A, W)
         plan.add('capmi_bcast_rows', _p(self.g), _p(self.X), beam, B, H, E + H, E, code)
-        lw = W('lstm_w')
-        ldl = E + 2 * H
-        wh = _p(lw) + (E + H) * es
-        hp, cp, hn, cn = _p(self.beam_h[0]), _p(self.beam_c[0]), _p(self.beam_h[1]), _p(self.beam_c[1])
-        plan.add('capmi_fill_f32', hp, 0.0, R * H * es // 4)         # h_{-1} = c_{-1} = 0 (:63)
-        plan.add('capmi_fill_f32', cp, 0.0, R * H * es // 4)
+        for l in range(self.L):
+            plan.add('capmi_fill_f32', _p(self.beam_h[l][0]), 0.0, R * H * es // 4)         # h_{-1} = c_{-1} = 0 (:63)
+            plan.add('capmi_fill_f32', _p(self.beam_c[l][0]), 0.0, R * H * es // 4)
         for t in range(Ti):
             sin, sout = self.beam_score[t % 2], self.beam_score[(t + 1) % 2]
             plan.add('capmi_embedding_fwd', _p(self.ids), _p(W('word_embedding')), _p(self.X), R, E, self.V, E + H, self.pad, code)
-            self._gemm(plan, _p(self.X), R, E + H, _p(lw), 4 * H, _p(self.G), ldw=ldl, bias=_p(st.view('lstm_b')))
-            self._gemm(plan, hp, R, H, wh, 4 * H, _p(self.G), ldw=ldl, addend=_p(self.G), ld_add=4 * H)
-            plan.add('capmi_lstm_cell_fwd', _p(self.G), cp, hn, cn, R, H, code)
+            xin = _p(self.X)
+            for l in range(self.L):
+                wn, bn, kin = self._lstm(l)
+                lw, ldl = W(wn), kin + H
+                hp, cp, hn, cn = _p(self.beam_h[l][0]), _p(self.beam_c[l][0]), _p(self.beam_h[l][1]), _p(self.beam_c[l][1])
+                self._gemm(plan, xin, R, kin, _p(lw), 4 * H, _p(self.G), ldw=ldl, bias=_p(st.view(bn)))
+                self._gemm(plan, hp, R, H, _p(lw) + kin * es, 4 * H, _p(self.G), ldw=ldl, addend=_p(self.G), ld_add=4 * H)
+                plan.add('capmi_lstm_cell_fwd', _p(self.G), cp, hn, cn, R, H, code)
+                xin = hn
             self._plan_post_lstm(plan, W, R, _p(self.X), hp, hn, cn)
             off = t * beam * B * 4
             plan.add('capmi_beam_step', _p(self.logits), self.V, self.Vld, B, beam, _p(sin), _p(sout), _p(self.beam_cand_val),
                      _p(self.beam_cand_idx), _p(self.beam_lse), _p(self.beam_parents) + off, _p(self.beam_tokens) + off,
                      _p(self.ids), _p(self.beam_rows))
-            plan.add('capmi_gather_rows', hn, _p(self.beam_rows), hp, R, H, code)      # survivors' state feeds the next step
-            plan.add('capmi_gather_rows', cn, _p(self.beam_rows), cp, R, H, code)
+            for l in range(self.L):       # survivors' state (every layer) feeds the next step
+                plan.add('capmi_gather_rows', _p(self.beam_h[l][1]), _p(self.beam_rows), _p(self.beam_h[l][0]), R, H, code)
+                plan.add('capmi_gather_rows', _p(self.beam_c[l][1]), _p(self.beam_rows), _p(self.beam_c[l][0]), R, H, code)
         plan.add('capmi_beam_backtrack', _p(self.beam_tokens), _p(self.beam_parents), _p(out_ids_f32), Ti, B, beam)
         self.beam_final_score = self.beam_score[Ti % 2]

@@ -30,13 +30,18 @@ def init_process_group_from_env(backend=None):
     os.environ.setdefault('MASTER_PORT', '29533')
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', rank))
-    if torch.cuda.is_available():
-        local %= torch.cuda.device_count()          # rehearsal on a box with fewer GPUs than ranks
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
         # 'nccl' is RCCL on ROCm; CAPMI_DIST_BACKEND=gloo rehearses the N > 1 path where RCCL cannot run (two ranks on one GPU)
         backend = os.environ.get('CAPMI_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        ndev = torch.cuda.device_count()
+        if local >= ndev:
+            if backend != 'gloo':       # RCCL refuses two ranks on one device, late and obscurely: say it here
+                raise RuntimeError('rank %d (LOCAL_RANK %d) has no GPU of its own: %d device(s) visible, WORLD_SIZE %d; several ranks '
+                                   'may share a GPU only for a gloo rehearsal (CAPMI_DIST_BACKEND=gloo)' % (rank, local, ndev, world))
+            local %= ndev               # gloo rehearsal on a box with fewer GPUs than ranks
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if not dist.is_initialized():
@@ -85,6 +90,57 @@ def allreduce_flat(flat, buckets, group=None, async_op=False):
     return works
 
 
+class NativeComm:
+    """The RCCL communicator behind capmi_allreduce_bucket (C ABI, include/capmi.h): one per process, on the current
+    device.  Rank 0's unique id travels through the torch.distributed group that launched the job (host channel only);
+    after that the gradient buckets never pass through torch.distributed.  `ok` is False -- with the reason in `why` --
+    when the library could not set the communicator up or its self-test (a sum of ones must equal the world size on
+    every rank) failed; the caller then keeps the torch.distributed all-reduce (the same RCCL underneath)."""
+
+    def __init__(self, pg, rank, world, device):
+        import ctypes
+        from . import _lib
+        self.ok, self.why, self.comm = False, '', ctypes.c_void_p()
+        L = _lib.lib()
+        ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
+        flag = torch.ones(1, dtype=torch.int32, device=device)
+        if rank == 0:
+            buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+            if L.capmi_comm_unique_id(buf) != 0:
+                self.why = _lib.last_error()
+                flag.zero_()
+            ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
+        ident = ident.to(device)
+        dist.broadcast(ident, src=0, group=pg)
+        dist.broadcast(flag, src=0, group=pg)
+        if int(flag.item()) == 0:
+            self.why = self.why or 'rank 0 could not create the RCCL unique id'
+            return
+        raw = bytes(ident.cpu().numpy().tobytes())
+        rc = L.capmi_comm_init(ctypes.byref(self.comm), world, rank, raw)
+        if rc != 0:
+            self.why = _lib.last_error()
+        else:       # self-test on the current stream
+            t = torch.ones(1024, dtype=torch.float32, device=device)
+            rc = L.capmi_allreduce_bucket(self.comm, t.data_ptr(), t.numel(), torch.cuda.current_stream(device).cuda_stream)
+            torch.cuda.synchronize(device)
+            if rc != 0:
+                self.why = _lib.last_error()
+            elif not bool((t == float(world)).all()):
+                rc, self.why = 1, 'self-test: sum of ones over %d ranks gave %r' % (world, float(t[0]))
+        good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(good, op=dist.ReduceOp.MIN, group=pg)          # all ranks take the same path
+        self.ok = bool(int(good.item()))
+        if not self.ok and not self.why:
+            self.why = 'another rank failed to set up its communicator'
+
+    def close(self):
+        from . import _lib
+        if self.comm:
+            _lib.lib().capmi_comm_destroy(self.comm)
+            self.comm = None
+
+
 class OverlappedTrainer:
     """Train step with the gradient all-reduce overlapped with backward (one instance per rank).
 
@@ -104,6 +160,17 @@ class OverlappedTrainer:
         prio = int(os.environ.get('CAPMI_COMM_PRIORITY', '0'))
         self.comm_stream = torch.cuda.Stream(device=engine.device, priority=prio) if self.active else None
         self._progs = {}
+        # backend nccl (= RCCL): the collective goes through the C ABI (capmi_allreduce_bucket) as rows of ONE launch table per
+        # step; any other backend (the gloo rehearsals) keeps torch.distributed and the per-segment replay below
+        self.native_comm = None
+        if self.active and dist.get_backend(engine.pg) == 'nccl' and os.environ.get('CAPMI_NATIVE_COMM', '1') != '0':
+            nc = NativeComm(engine.pg, dist.get_rank(engine.pg), dist.get_world_size(engine.pg), engine.device)
+            if nc.ok:
+                self.native_comm = nc
+            else:
+                import sys
+                print('capmi: RCCL communicator behind the C ABI unavailable (%s); gradient buckets go through torch.distributed'
+                      % nc.why, file=sys.stderr)
 
     def _prepare(self, B):
         from ._lib import Plan
@@ -130,7 +197,36 @@ class OverlappedTrainer:
             segs.append((sub, (b, e), {}))
             start = stop
         assert start == len(bwd)
-        return dict(prog=prog, segs=segs, fwd_graph={})
+        P = dict(prog=prog, segs=segs, fwd_graph={})
+        if self.native_comm is not None:
+            P['step'], P['lrt'] = self._fuse_step(prog, segs)
+        return P
+
+    def _fuse_step(self, prog, segs):
+        """The whole data-parallel step as ONE launch plan on three lanes: forward, then per bucket the backward segment
+        (lanes 0/1) followed -- on lane 2, behind events of both -- by capmi_allreduce_bucket, Adam (1/N folded in) and the
+        shadow refresh of that bucket's parameters.  Nothing on lanes 0/1 ever waits for lane 2 inside a step: the
+        all-reduces and the optimizer hide under the remaining backward pass; the plan's final join makes the next
+        forward wait for the refreshed weights."""
+        import ctypes
+        from ._lib import Plan
+        eng = self.eng
+        st = eng.store
+        lrt = ctypes.c_float(0.0)
+        total = st.trainable_size
+        step = Plan()
+        step.extend(prog['fwd'])
+        for i, (sub, (b, e), _) in enumerate(segs):
+            step.extend(sub)
+            step.record(('bucket', i, 0), 0)
+            step.wait(('bucket', i, 0), 2)
+            if sub.has_lanes:                       # the segment's weight gradients (lane 1) are part of the bucket
+                step.record(('bucket', i, 1), 1)
+                step.wait(('bucket', i, 1), 2)
+            step.add('capmi_allreduce_bucket', self.native_comm.comm, st.grad.data_ptr() + b * 4, e - b, lane=2)
+            eng.plan_adam(step, b, e, lrt, 2, grad_scale=1.0 / eng.world)
+            eng.plan_shadow(step, b, st.size if e == total else e, 2)
+        return step, lrt
 
     def train_step(self, image, caption):
         eng = self.eng
@@ -145,6 +241,13 @@ class OverlappedTrainer:
             eng.refresh_shadows()
         eng._feed_train(prog, image, caption)
         from .optim import adam_lr_t
+        if 'step' in P:         # RCCL through the C ABI: one launch table per step
+            lr = eng.lr_schedule.value(eng.step_count)
+            eng.step_count += 1
+            P['lrt'].value = adam_lr_t(lr, eng.step_count)
+            P['step'].run(eng._stream())
+            eng.shadows_dirty = False
+            return prog['dec'].loss, lr
         cur = torch.cuda.current_stream(eng.device)
         eng._run_captured(P['fwd_graph'], 'g', prog['fwd_parts'] if eng.graph_decoder_forward else [prog['fwd']])
         grad = eng.store.grad
@@ -154,7 +257,9 @@ class OverlappedTrainer:
         total = eng.store.trainable_size
         for sub, (b, e), holder in P['segs']:
             eng._run_captured(holder, 'g', [sub])
-            ev = torch.cuda.Event()
+            ev = holder.get('event')
+            if ev is None:
+                ev = holder['event'] = torch.cuda.Event()      # one event per segment, re-recorded every step
             ev.record(cur)
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):

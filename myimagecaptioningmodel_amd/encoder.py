@@ -436,7 +436,7 @@ class EncoderRunner:
                 dwt = st.gview(op.name + '_weights')
                 if op.src == 0:
                     plan.add('capmi_igemm_tn_wgrad', _p(self.s2d), _p(draw), _p(dwt), self._stem_geom(op), c, c, self.kpad_of(op),
-                             _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code, lane=wl)
+                             _p(wgrad_workspace(self.dev, wl)), WGRAD_WS_BYTES, code, lane=wl)
                     plan.add('capmi_s2d_stem_mask_grad', _p(dwt), c, op.cin, op.k, self.stem_cs, lane=wl)
                     if wl and not ln:
                         plan.record(('wgrad', op.name), 1)
@@ -453,7 +453,7 @@ class EncoderRunner:
                 else:
                     g = self._conv_geom(op)
                     K = op.k * op.k * op.cin
-                    plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(draw), _p(dwt), g, c, c, K, _p(wgrad_workspace(self.dev)), WGRAD_WS_BYTES, code, lane=wl)
+                    plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(draw), _p(dwt), g, c, c, K, _p(wgrad_workspace(self.dev, wl)), WGRAD_WS_BYTES, code, lane=wl)
                     if wl and not ln:
                         plan.record(('wgrad', op.name), 1)
                     t = op.src

@@ -197,8 +197,9 @@ class CaptionEngine:
         enc.plan_forward(plan, image, self.W, update_running=not is_test, is_test=is_test)
         if beam <= 1:
             es = dec.Hbuf.element_size()
-            plan.add('capmi_fill_f32', _p(dec.Hbuf), 0.0, B * dec.H * es // 4)
-            plan.add('capmi_fill_f32', _p(dec.Cbuf), 0.0, B * dec.H * es // 4)
+            for hb, cb in zip(dec.Hbufs, dec.Cbufs):                                 # zero state of every LSTM layer (:63)
+                plan.add('capmi_fill_f32', _p(hb), 0.0, B * dec.H * es // 4)
+                plan.add('capmi_fill_f32', _p(cb), 0.0, B * dec.H * es // 4)
             dec.plan_greedy(plan, enc.out_tensor(), self.W, out, Ti)
         else:
             dec.plan_beam(plan, enc.out_tensor(), self.W, out, Ti, beam)
@@ -328,6 +329,24 @@ class CaptionEngine:
         if self.world > 1:
             torch.distributed.all_reduce(self.store.grad[:self.store.trainable_size], group=self.pg)
 
+    def plan_adam(self, plan, b, e, lrt, lane, grad_scale=1.0):
+        """Adam over flat range [b, e) as a plan entry; lrt: a ctypes.c_float re-read before every run."""
+        st, cfg = self.store, self.cfg
+        clip = float(cfg['gradient_clip']) if cfg.get('gradient_clip') else 0.0
+        if e > b:
+            plan.add('capmi_adam', st.flat.data_ptr() + b * 4, st.grad.data_ptr() + b * 4, st.adam_m.data_ptr() + b * 4,
+                     st.adam_v.data_ptr() + b * 4, e - b, lrt, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, grad_scale, lane=lane)
+
+    def plan_shadow(self, plan, b, e, lane):
+        """Refresh of the bf16 shadow and of the data-gradient weight forms whose source lies in flat range [b, e)."""
+        st = self.store
+        if self.low is not None and e > b:
+            plan.add('capmi_cast', st.flat.data_ptr() + b * 4, self.low.data_ptr() + b * self.low.element_size(), e - b, self.code, lane=lane)
+        j0 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= b), len(self.dgrad_job_src))
+        j1 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= e), len(self.dgrad_job_src))
+        if j1 > j0:
+            plan.add('capmi_weight_dgrad_form_batched', _p(st.flat), _p(self.wT), self.dgrad_jobs.data_ptr() + j0 * 56, j1 - j0, self.code, lane=lane)
+
     def _build_fused_bwd(self, prog):
         """Backward plan with the optimizer inside (single-rank training): once ~90 % of the parameters have
         their final gradients, Adam + the shadow refresh of that range run on the side lane under the rest
@@ -343,22 +362,12 @@ class CaptionEngine:
                 cut_idx, cut = idx, off
                 break
         lrt = ctypes.c_float(0.0)
-        clip = float(cfg['gradient_clip']) if cfg.get('gradient_clip') else 0.0
-        es4 = 4
 
         def optimizer_range(plan, b, e, lane):
-            if e <= b:
-                return
-            plan.add('capmi_adam', st.flat.data_ptr() + b * es4, st.grad.data_ptr() + b * es4, st.adam_m.data_ptr() + b * es4,
-                     st.adam_v.data_ptr() + b * es4, e - b, lrt, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, 1.0, lane=lane)
+            self.plan_adam(plan, b, e, lrt, lane)
 
         def shadow_range(plan, b, e, lane):
-            if self.low is not None and e > b:
-                plan.add('capmi_cast', st.flat.data_ptr() + b * es4, self.low.data_ptr() + b * self.low.element_size(), e - b, self.code, lane=lane)
-            j0 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= b), len(self.dgrad_job_src))
-            j1 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= e), len(self.dgrad_job_src))
-            if j1 > j0:
-                plan.add('capmi_weight_dgrad_form_batched', _p(st.flat), _p(self.wT), self.dgrad_jobs.data_ptr() + j0 * 56, j1 - j0, self.code, lane=lane)
+            self.plan_shadow(plan, b, e, lane)
 
         fused = Plan()
         head = Plan()
@@ -386,7 +395,7 @@ class CaptionEngine:
         """feed -> fwd -> bwd -> (all-reduce) -> Adam; returns (loss tensor [1], lr float)."""
         lanes_on = self.overlap_lanes and os.environ.get('CAPMI_LANES', '1') != '0'
         # (a captured graph would freeze this step's learning rate: the fused plan is only ever launched eagerly)
-        if self.world == 1 and self.fuse_optimizer and self.cfg['encoder_trainable'] and (lanes_on or not self.use_graph):
+        if self.world == 1 and self.pg is None and self.fuse_optimizer and (lanes_on or not self.use_graph):
             B = int(image.shape[0])
             prog = self._train.get(B)
             if prog is None:

@@ -19,7 +19,25 @@ class LRSchedule:
         self.strategy, self.base_lr = strategy, float(base_lr)
         self.step_each_epoch = max(1, math.ceil(sample_cnt / batch_size)) if sample_cnt else 1   # util.py:24
         self.decay_epoch, self.warmup_epoch, self.max_epoch = decay_epoch, warmup_epoch, max_epoch
-        self.cur_epoch = 0.0          # the persistable `cur_epoch` var of util.py:94-95
+
+    # ---- the two persistable scalars behind the schedules, as pure functions of the number of steps taken
+    def counter_begin(self):
+        """`begin` of `_decay_step_counter` for this strategy (util.py:47-51,55,98: the warm-up forms count from 1;
+        fluid.layers.cosine_decay and cosine_decay_restart from 0)."""
+        return 1 if self.strategy in ('cosine_decay_warmup', 'cosine_decay_restart_warmup') else 0
+
+    def counter_after(self, steps_taken):
+        """Value held by `@LR_DECAY_COUNTER@` after `steps_taken` runs of the train program: the variable starts at
+        begin - 1 and is incremented inside every run (Paddle autoincreased_step_counter, from memory)."""
+        return self.counter_begin() - 1 + int(steps_taken)
+
+    def steps_from_counter(self, counter):
+        return max(0, int(counter) - self.counter_begin() + 1)
+
+    def cur_epoch_after(self, steps_taken):
+        """The persistable `cur_epoch` of util.py:94-101 after `steps_taken` runs: it starts at 0 and gains 1 in
+        every run whose counter value g (= 1, 2, ...) satisfies g % step_each_epoch == 0."""
+        return float(int(steps_taken) // self.step_each_epoch)
 
     @staticmethod
     def _restart_fraction(completed_fraction, t_mul=2.0):
@@ -29,7 +47,8 @@ class LRSchedule:
         return (completed_fraction - sum_r) / t_mul ** i_restart
 
     def value(self, step):
-        """lr used by training step number `step` (0-based count of steps already taken)."""
+        """lr used by training step number `step` (0-based count of steps already taken).  Pure: calling it twice, or
+        out of order, changes nothing (the reference keeps `cur_epoch` as a persistable; here it is derived)."""
         s, lr = self.strategy, self.base_lr
         if s is None:
             return lr                                                            # util.py:43-44
@@ -46,13 +65,14 @@ class LRSchedule:
             cur_epoch = math.floor(step / self.step_each_epoch)
             frac = self._restart_fraction(cur_epoch / self.decay_epoch)
             return lr * 0.5 * (math.cos(math.pi * frac) + 1)
-        # cosine_decay_restart_warmup, util.py:92-119: counter from 1; cur_epoch += 1 when step % spe == 0
+        # cosine_decay_restart_warmup, util.py:92-119: counter from 1; cur_epoch += 1 in the run whose counter g = step + 1
+        # is a multiple of step_each_epoch, BEFORE the lr of that run is formed (:99-101) -- so run `step` sees
+        # cur_epoch = floor((step + 1) / spe): a pure function of the step, like the other strategies
         start_lr = 0.00001
-        if (step + 1) % self.step_each_epoch <= 0:
-            self.cur_epoch += 1
-        if self.cur_epoch < self.warmup_epoch:
-            return start_lr + (lr - start_lr) * (self.cur_epoch / float(self.warmup_epoch))
-        frac = self._restart_fraction((self.cur_epoch - self.warmup_epoch) / self.decay_epoch)
+        cur_epoch = self.cur_epoch_after(step + 1)
+        if cur_epoch < self.warmup_epoch:
+            return start_lr + (lr - start_lr) * (cur_epoch / float(self.warmup_epoch))
+        frac = self._restart_fraction((cur_epoch - self.warmup_epoch) / self.decay_epoch)
         return lr * 0.5 * (math.cos(math.pi * frac) + 1)
 
 

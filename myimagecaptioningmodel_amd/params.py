@@ -41,7 +41,7 @@ def stem_s2d(k, cin):
     return (k + 1) // 2, (4 * cin + 7) // 8 * 8
 
 
-def decoder_param_specs(C, H, E, V):
+def decoder_param_specs(C, H, E, V, rnn_layer=1):
     """(name, ref_shape, kind) for the bridge + decoder, reference creation order."""
     specs = []
 
@@ -55,6 +55,9 @@ def decoder_param_specs(C, H, E, V):
     fc('img_feat_emb', H, H)    # :53
     specs.append(('lstm_w', (E + H + H, 4 * H), 'fc_w'))     # :87-88 (fc_4 renamed by param_attr)
     specs.append(('lstm_b', (4 * H,), 'vec'))
+    for l in range(1, rnn_layer):     # build-defined stacked layers (BASELINE configs[3]); the reference never reads rnn_layer (:42,46,174)
+        specs.append(('lstm_w_l%d' % l, (H + H, 4 * H), 'fc_w'))
+        specs.append(('lstm_b_l%d' % l, (4 * H,), 'vec'))
     fc('p_word', E + H, H)      # :89
     fc('p_hidden', H, H)        # :90
     fc('p_hid', H, H)           # :99
@@ -159,7 +162,7 @@ class ParamStore:
             self.entries[name] = Entry(name, off, ks, tuple(ref_shape), kind, trainable)
             off += (int(np.prod(ks)) + ALIGN - 1) // ALIGN * ALIGN
 
-        for name, shp, kind in decoder_param_specs(self.enc.channels, H, E, V):
+        for name, shp, kind in decoder_param_specs(self.enc.channels, H, E, V, int(cfg.get('rnn_layer', 1))):
             add(name, shp, kind, True)
         self.decoder_size = off
         enc_params, enc_state = encoder_param_specs(self.enc)

@@ -25,9 +25,14 @@ def default_cfg(**kw):
     """Repo-default hyper-parameters (IC/config.py:15,22-24,50,55-60)."""
     cfg = dict(encoder='mobilenetv2', image_size=224, hidden=1024, embed=256, vocab=12295,
                sentence_length=35, infer_max_length=35, start_idx=2, stop_idx=3, padding_idx=0,
-               encoder_trainable=True, attention='singleton')
+               encoder_trainable=True, attention='singleton', rnn_layer=1)
     cfg.update(kw)
     return cfg
+
+
+def lstm_names(layer):
+    """(weight, bias) variable names of LSTM layer `layer` (0 = the reference's only layer, :87-88)."""
+    return ('lstm_w', 'lstm_b') if layer == 0 else ('lstm_w_l%d' % layer, 'lstm_b_l%d' % layer)
 
 
 def param_shapes(cfg):
@@ -49,6 +54,12 @@ def param_shapes(cfg):
         shapes[name + '.b_0'] = (o,)
     shapes['lstm_w'] = (E + H + H, 4 * H)      # model_adaAttention_aic.py:87-88
     shapes['lstm_b'] = (4 * H,)
+    # BUILD-DEFINED extension (BASELINE configs[3]; the reference stores `rnn_layer` and never reads it, :42,46,174):
+    # layer l >= 1 is another lstm_unit whose input is the hidden state of layer l-1 at the same step
+    for l in range(1, cfg.get('rnn_layer', 1)):
+        w, b = lstm_names(l)
+        shapes[w] = (H + H, 4 * H)
+        shapes[b] = (4 * H,)
     shapes['word_embedding'] = (V, E)          # :16-19, shared with :29-32
     shapes['out_fc_bias'] = (V,)               # :20-23
     return shapes
@@ -180,11 +191,28 @@ class OracleModel:
         return ex / ex.sum(1, keepdims=True)
 
     def _step_fwd(self, word, g, hid, cell, Vt, Ve):
-        """One body of the While loop, model_adaAttention_aic.py:84-117."""
+        """One body of the While loop, model_adaAttention_aic.py:84-117.
+
+        rnn_layer = 1 (the reference): hid / cell are [B,H] arrays.  rnn_layer = L > 1 (build-defined stacked
+        extension): hid / cell are [L,B,H]; layer 0 is the reference's lstm_unit on [emb ; g], layer l its own
+        lstm_unit on the NEW hidden state of layer l-1; everything after the LSTM (sentinel gate :89-92,
+        attention, output head) reads the TOP layer -- its previous hidden state, new hidden state, new cell."""
         p, cfg = self.p, self.cfg
         emb = ops.embedding_fwd(word, p['word_embedding'], cfg['padding_idx'])       # :84
         xt = np.concatenate([emb, g], axis=-1)                                        # :86
-        h, c, lcache = ops.lstm_unit_fwd(xt, hid, cell, p['lstm_w'], p['lstm_b'])     # :87-88
+        nl = cfg.get('rnn_layer', 1)
+        if nl == 1:
+            h, c, lcache = ops.lstm_unit_fwd(xt, hid, cell, p['lstm_w'], p['lstm_b'])     # :87-88
+            lcaches, h_state, c_state = [lcache], h, c
+        else:
+            hs, cs, lcaches, xin = [], [], [], xt
+            for l in range(nl):
+                wn, bn = lstm_names(l)
+                hl, cl, lc = ops.lstm_unit_fwd(xin, hid[l], cell[l], p[wn], p[bn])
+                hs.append(hl), cs.append(cl), lcaches.append(lc)
+                xin = hl
+            h_state, c_state = np.stack(hs), np.stack(cs)
+            hid, h, c = hid[nl - 1], hs[-1], cs[-1]
         sg = ops.sigmoid(ops.fc_fwd(xt, p[FC_P_WORD + '.w_0'], p[FC_P_WORD + '.b_0'])
                          + ops.fc_fwd(hid, p[FC_P_HIDDEN + '.w_0'], p[FC_P_HIDDEN + '.b_0']))  # :89-91
         tc = np.tanh(c)
@@ -202,9 +230,15 @@ class OracleModel:
         out = np.tanh(ops.fc_fwd(ctxp, p[FC_OUT + '.w_0'], p[FC_OUT + '.b_0']))       # :115
         proj = ops.fc_fwd(out, p[FC_PROJ + '.w_0'], p[FC_PROJ + '.b_0'])              # :24
         logits = proj @ p['word_embedding'].T + p['out_fc_bias']                      # :25
-        cache = dict(word=word, xt=xt, hid_prev=hid, lcache=lcache, sg=sg, tc=tc, sentinel=sentinel,
+        cache = dict(word=word, xt=xt, hid_prev=hid, lcaches=lcaches, sg=sg, tc=tc, sentinel=sentinel,
                      h=h, p_hid=p_hid, z=z, alpha=alpha, ctx_all=ctx_all, ctxp=ctxp, out=out, proj=proj)
-        return h, c, logits, cache
+        return h_state, c_state, logits, cache
+
+    def _zero_state(self, B):
+        """create_zero_state (:35-37, :63); one (h, c) pair per layer."""
+        nl, H = self.cfg.get('rnn_layer', 1), self.cfg['hidden']
+        shape = (B, H) if nl == 1 else (nl, B, H)
+        return np.zeros(shape, self.dtype), np.zeros(shape, self.dtype)
 
     # ------------------------------------------------------------------ train forward (:161-183)
     def forward_train(self, image, caption, update_stats=True):
@@ -220,8 +254,7 @@ class OracleModel:
         Vt = np.tanh(ops.fc_fwd(V0, p[FC_IMG_FEAT + '.w_0'], p[FC_IMG_FEAT + '.b_0']))       # :52
         Ve = ops.fc_fwd(V0, p[FC_IMG_FEAT_EMB + '.w_0'], p[FC_IMG_FEAT_EMB + '.b_0'])        # :53
         B = image.shape[0]
-        hid = np.zeros((B, cfg['hidden']), dt)                                        # :63
-        cell = np.zeros((B, cfg['hidden']), dt)
+        hid, cell = self._zero_state(B)                                               # :63
         T = cfg['sentence_length'] - 1                                                # :66
         steps, logits = [], []
         for s in range(T):                                                            # :75-127
@@ -251,8 +284,9 @@ class OracleModel:
         dVt = np.zeros_like(Vt)
         dVe = np.zeros_like(Ve)
         dg = np.zeros_like(g)
-        dh_next = np.zeros_like(g)
-        dc_next = np.zeros_like(g)
+        nl = cfg.get('rnn_layer', 1)
+        dh_next = [np.zeros_like(g) for _ in range(nl)]       # per layer: d loss / d h_{t-1}, d c_{t-1} from step t
+        dc_next = [np.zeros_like(g) for _ in range(nl)]
 
         def fcb(name, dy, x):
             dx, dw, db = ops.fc_bwd(dy, x, p[name + '.w_0'])
@@ -284,18 +318,23 @@ class OracleModel:
             dVe += dzpre[:, :K]
             dsent += fcb(FC_SENT_EMB, dzpre[:, K], c['sentinel'])
             dp_hid += fcb(FC_HID_EMB, dzpre.sum(1), c['p_hid'])
-            dh = fcb(FC_P_HID, dp_hid * (1 - c['p_hid'] ** 2), c['h']) + dh_next
+            dh = fcb(FC_P_HID, dp_hid * (1 - c['p_hid'] ** 2), c['h']) + dh_next[nl - 1]
             dsg = dsent * c['tc']
-            dc = dsent * c['sg'] * (1 - c['tc'] ** 2) + dc_next
+            dc = dsent * c['sg'] * (1 - c['tc'] ** 2) + dc_next[nl - 1]
             dsgpre = dsg * c['sg'] * (1 - c['sg'])
             dxt = fcb(FC_P_WORD, dsgpre, c['xt'])
             dhid_prev = fcb(FC_P_HIDDEN, dsgpre, c['hid_prev'])
-            dxt2, dh_prev2, dc_prev, dlw, dlb = ops.lstm_unit_bwd(dh, dc, c['lcache'], p['lstm_w'])
-            grads['lstm_w'] += dlw
-            grads['lstm_b'] += dlb
-            dxt = dxt + dxt2
-            dh_next = dhid_prev + dh_prev2
-            dc_next = dc_prev
+            for l in reversed(range(nl)):                       # top layer first; layer l's input gradient is d h of layer l-1
+                wn, bn = lstm_names(l)
+                dxin, dh_prev_l, dc_prev_l, dlw, dlb = ops.lstm_unit_bwd(dh, dc, c['lcaches'][l], p[wn])
+                grads[wn] += dlw
+                grads[bn] += dlb
+                dh_next[l] = dh_prev_l + (dhid_prev if l == nl - 1 else 0.0)
+                dc_next[l] = dc_prev_l
+                if l > 0:
+                    dh, dc = dxin + dh_next[l - 1], dc_next[l - 1]      # (still step t+1's values: overwritten below)
+                else:
+                    dxt = dxt + dxin
             grads['word_embedding'] += ops.embedding_bwd(dxt[:, :E], c['word'],
                                                          p['word_embedding'].shape, cfg['padding_idx'])
             dg += dxt[:, E:]
@@ -336,8 +375,7 @@ class OracleModel:
         Vt = np.tanh(ops.fc_fwd(V0, p[FC_IMG_FEAT + '.w_0'], p[FC_IMG_FEAT + '.b_0']))
         Ve = ops.fc_fwd(V0, p[FC_IMG_FEAT_EMB + '.w_0'], p[FC_IMG_FEAT_EMB + '.b_0'])
         B = image.shape[0]
-        hid = np.zeros((B, cfg['hidden']), dt)
-        cell = np.zeros((B, cfg['hidden']), dt)
+        hid, cell = self._zero_state(B)
         word = np.full((B,), cfg['start_idx'], np.int64)
         out, all_logits = [], []
         for _ in range(cfg['infer_max_length']):
@@ -365,8 +403,7 @@ class OracleModel:
         B, Ti, V = image.shape[0], cfg['infer_max_length'], cfg['vocab']
         rep = lambda x: np.concatenate([x] * beam, axis=0)                # rows k*B + b (beam-major)
         g_, Vt_, Ve_ = rep(g), rep(Vt), rep(Ve)
-        hid = np.zeros((beam * B, cfg['hidden']), dt)
-        cell = np.zeros((beam * B, cfg['hidden']), dt)
+        hid, cell = self._zero_state(beam * B)
         word = np.full((beam * B,), cfg['start_idx'], np.int64)
         score = np.full((beam, B), -1e30, np.float64)
         score[0] = 0.0
@@ -383,7 +420,7 @@ class OracleModel:
             par, tok = best // V, best % V                                                 # [B, beam]
             score = np.take_along_axis(tot, best, 1).T.copy()                              # [beam, B]
             src = (par.T * B + np.arange(B)[None, :]).reshape(-1)                          # row of the parent state
-            hid, cell = hid[src], cell[src]
+            hid, cell = hid[..., src, :], cell[..., src, :]
             word = tok.T.reshape(-1).astype(np.int64)
             tokens.append(tok.T.copy())
             parents.append(par.T.copy())

@@ -1,4 +1,5 @@
-"""BASELINE.json configs[1] at FULL size (ResNet-50, 224x224, batch 64, vocab 10 000, seq_len 20, bf16) on the MI355X.
+"""BASELINE.json configs[1] (ResNet-50, 224x224, batch 64, vocab 10 000, seq_len 20, bf16) and configs[3] (ResNet-101 +
+2-layer 1024-d LSTM decoder, 384x384, seq_len 30, vocab 20 000, 64 images per GPU, bf16) at FULL size on the MI355X.
 The NumPy oracle needs minutes per step there, so parity is checked through size-independent properties of the
 reference graph (SURVEY.md 8c(2) known answers, model_adaAttention_aic.py line numbers in each test) plus agreement
 between the engine's own execution modes; the small-size tests in test_gpu_model.py hold the oracle comparison."""
@@ -17,14 +18,19 @@ pytestmark = pytest.mark.gpu
 B = bench.PER_GPU_BATCH
 
 
-@pytest.fixture(scope='module')
-def full():
+WORKLOADS = {'configs1_resnet50_224': bench.WORKLOAD, 'configs3_resnet101_384_2layer': bench.WORKLOAD_CFG3}
+
+
+@pytest.fixture(scope='module', params=list(WORKLOADS))
+def full(request):
     from myimagecaptioningmodel_amd import default_cfg
     from myimagecaptioningmodel_amd.model import CaptionEngine
-    cfg = default_cfg(batch_size=B, sample_count=0, **bench.WORKLOAD)
+    cfg = default_cfg(batch_size=B, sample_count=0, **WORKLOADS[request.param])
     eng = CaptionEngine(cfg, device='cuda:0', use_graph=False)
     image, cap = bench.synthetic_batch(B, cfg, 1234)
-    return cfg, eng, image, cap, eng.export_reference_params()
+    yield cfg, eng, image, cap, eng.export_reference_params()
+    del eng
+    torch.cuda.empty_cache()
 
 
 def _loss(eng, image, cap):
@@ -116,7 +122,8 @@ def test_inference_decode_is_idempotent_and_beam_one_is_greedy(full):
     assert ((a >= 0) & (a < cfg['vocab'])).all()
 
 
-def test_every_encoder_layer_in_situ_against_torch_matmul(monkeypatch):
+@pytest.mark.parametrize('workload', list(WORKLOADS))
+def test_every_encoder_layer_in_situ_against_torch_matmul(monkeypatch, workload):
     """Layer-local parity at full size, immune to the sensitivity of the random-init network (a batch permutation alone
     moves the f32 conv gradients by 1e-2 and decorrelates the bf16 ones: batch norm over 64 near-identical noise images
     amplifies rounding by 1e5 -- DESIGN.md section 5): after ONE bf16 train step every convolution's output, batch-norm
@@ -128,8 +135,9 @@ def test_every_encoder_layer_in_situ_against_torch_matmul(monkeypatch):
     import torch.nn.functional as F
     from myimagecaptioningmodel_amd import arch, default_cfg
     from myimagecaptioningmodel_amd.model import CaptionEngine
-    monkeypatch.setenv('CAPMI_RING', '64')
-    cfg = default_cfg(batch_size=B, sample_count=0, **bench.WORKLOAD)
+    monkeypatch.setenv('CAPMI_RING', '128')
+    cfg = default_cfg(batch_size=B, sample_count=0, **WORKLOADS[workload])
+    n_conv = {'resnet50': 53, 'resnet101': 104}[cfg['encoder']]
     eng = CaptionEngine(cfg, device='cuda:0', use_graph=False)
     image, cap = bench.synthetic_batch(B, cfg, 1234)
     eng.forward_backward(image, cap)
@@ -237,7 +245,9 @@ def test_every_encoder_layer_in_situ_against_torch_matmul(monkeypatch):
             del gcols, dx_ref
         del cols, ref, raw, y, got, dy, dz, xhat, dy_ref
     print('in-situ layers checked', checked, 'worst relative L2 errors', worst)
-    assert checked['conv'] == 53 and checked['wgrad'] >= 50 and checked['bn_bwd'] >= 50 and checked['dgrad'] >= 30
+    assert checked['conv'] == n_conv and checked['wgrad'] >= n_conv - 3 and checked['bn_bwd'] >= n_conv - 3 and checked['dgrad'] >= (n_conv - 5) * 2 // 3 - 3
+    del eng
+    torch.cuda.empty_cache()
 
 
 def test_bf16_step_agrees_with_the_f32_engine_where_the_model_allows(full):
@@ -249,13 +259,13 @@ def test_bf16_step_agrees_with_the_f32_engine_where_the_model_allows(full):
     cfg, eng, image, cap, params = full
     l16 = _loss(eng, image, cap)
     g16 = eng.export_reference_grads()
-    wl = dict(bench.WORKLOAD, dtype='f32')
-    e32 = CaptionEngine(default_cfg(batch_size=B, sample_count=0, **wl), device='cuda:0', use_graph=False)
+    e32 = CaptionEngine(dict(cfg, dtype='f32'), device='cuda:0', use_graph=False)
     e32.load_reference_params(params)
     l32 = _loss(e32, image, cap)
     g32 = e32.export_reference_grads()
     assert abs(l16 - l32) <= 5e-2, (l16, l32)
-    for k, bound in (('lstm_w', 0.995), ('word_embedding', 0.995), ('fc_1.w_0', 0.99), ('fc_0.w_0', 0.98), ('fc_7.w_0', 0.995),
+    extra = (('lstm_w_l1', 0.995),) if cfg.get('rnn_layer', 1) > 1 else ()
+    for k, bound in extra + (('lstm_w', 0.995), ('word_embedding', 0.995), ('fc_1.w_0', 0.99), ('fc_0.w_0', 0.98), ('fc_7.w_0', 0.995),
                      ('fc_11.w_0', 0.995), ('fc_12.w_0', 0.995), ('out_fc_bias', 0.995)):
         a, b = g16[k].astype(np.float64).ravel(), g32[k].astype(np.float64).ravel()
         cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b)))
@@ -263,16 +273,18 @@ def test_bf16_step_agrees_with_the_f32_engine_where_the_model_allows(full):
         assert abs(np.linalg.norm(a) / np.linalg.norm(b) - 1) < 0.05, (k, np.linalg.norm(a), np.linalg.norm(b))
 
 
-def test_training_on_a_fixed_batch_drives_the_loss_down():
+@pytest.mark.parametrize('workload', list(WORKLOADS))
+def test_training_on_a_fixed_batch_drives_the_loss_down(workload):
     """The whole step (forward, backward, Paddle-form Adam, weight-shadow refresh; two lanes, fused optimizer) as
     bench.py runs it: 40 steps on one synthetic batch take the loss from ~12 (random init, ln V = 9.2) to below 3, and
     the single-stream order (CAPMI_LANES=0, optimizer as separate launches) follows the same trajectory."""
     import os
     from myimagecaptioningmodel_amd import default_cfg
     from myimagecaptioningmodel_amd.model import CaptionEngine
-    cfg = default_cfg(batch_size=B, sample_count=0, **bench.WORKLOAD)
+    cfg = default_cfg(batch_size=B, sample_count=0, **WORKLOADS[workload])
     image, cap = bench.synthetic_batch(B, cfg, 1234)
     image_d, cap_d = torch.as_tensor(image).cuda(), torch.as_tensor(cap).cuda()
+    lnv = math.log(cfg['vocab'])
     curves = []
     for lanes in ('1', '0'):
         os.environ['CAPMI_LANES'] = lanes
@@ -284,7 +296,8 @@ def test_training_on_a_fixed_batch_drives_the_loss_down():
             os.environ.pop('CAPMI_LANES', None)
     for c in curves:
         assert all(np.isfinite(c)), c
-        assert 11.0 < c[0] < 13.0 and c[-1] < 3.0, (c[0], c[-1])
-        assert c[20] < c[0] - 3.0
+        assert lnv + 1.0 < c[0] < lnv + 15.0 and c[-1] < 0.5 * c[0], (c[0], c[-1])
+        assert c[20] < c[0] - 2.0
+        print(workload, 'loss curve', [round(x, 3) for x in c[::5]])
     # same arithmetic in another launch order: the curves stay together (bf16 + chaotic early steps: not bit for bit)
     assert abs(curves[0][-1] - curves[1][-1]) < 0.5, (curves[0][-1], curves[1][-1])

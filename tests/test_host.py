@@ -32,7 +32,10 @@ def test_library_exports_every_header_symbol_with_matching_signature():
             continue
         if name == 'capmi_igemm_tn_ws_bytes':
             continue
-        sig = _lib.SIGNATURES.get(name) or _lib.QUERIES.get(name) or _lib.SYNC.get(name)
+        if name.startswith('capmi_plan_'):        # bound by hand in _lib.lib() (struct pointer / string results); used below
+            assert getattr(L, name).argtypes is not None or name == 'capmi_plan_entry_count'
+            continue
+        sig = _lib.SIGNATURES.get(name) or _lib.QUERIES.get(name) or _lib.SYNC.get(name) or _lib.COMM.get(name)
         assert sig is not None, 'no ctypes signature for %s' % name
         arglist = [a.strip() for a in args.split(',') if a.strip() and a.strip() != 'void']
         assert len(sig) == len(arglist), (name, len(sig), len(arglist))
@@ -54,7 +57,41 @@ def test_library_exports_every_header_symbol_with_matching_signature():
             assert t is exp, (name, a)
     # and nothing bound that the header does not declare
     declared = {n for n, _ in decls}
-    assert set(_lib.SIGNATURES) | set(_lib.QUERIES) | set(_lib.SYNC) <= declared
+    assert set(_lib.SIGNATURES) | set(_lib.QUERIES) | set(_lib.SYNC) | set(_lib.COMM) <= declared
+    # the plan entry table (capmi_plan_run) covers every stream-taking entry point, with the arity the binding has
+    assert set(_lib.PLAN_ENTRIES) == set(_lib.SIGNATURES)
+    assert ctypes.sizeof(_lib.Launch) == 16 + 8 * _lib.PLAN_MAX_ARGS
+    assert max(len(v) for v in _lib.SIGNATURES.values()) - 1 <= _lib.PLAN_MAX_ARGS
+
+
+def test_plan_table_packs_arguments_and_reports_bad_rows():
+    """capmi_plan_run without a GPU: the packed table of a recorded plan (slots: pointers, two's-complement ints, float
+    bits, host struct addresses; patch points for ctypes floats) and the runner's argument checks."""
+    from myimagecaptioningmodel_amd import _lib
+    L = _lib.lib()
+    p = _lib.Plan()
+    g = _lib.gemm_geom(8, 16)
+    lrt = ctypes.c_float(0.25)
+    p.add('capmi_igemm_nt', 4096, 8192, 12288, g, 32, 16, 32, None, None, 0, None, 0, None, 0, 0, 0, _lib.F32)
+    p.add('capmi_adam', 64, 128, 192, 256, 1000, lrt, 0.9, 0.999, 1e-8, 0.0, 1.0)
+    p.add('capmi_embedding_fwd', 64, 128, 192, 4, 8, 50, 24, -1, _lib.F32)
+    c = p._compile(False)
+    t = c['table']
+    assert c['n'] == 3 and [t[i].kind for i in range(3)] == [0, 0, 0] and [t[i].lane for i in range(3)] == [0, 0, 0]
+    assert t[0].entry == _lib.PLAN_ENTRIES['capmi_igemm_nt'] and t[0].nargs == 17
+    assert t[0].args[0] == 4096 and t[0].args[3] == ctypes.addressof(g) and t[0].args[7] == 0
+    assert t[1].args[5] == _lib._float_bits(0.25) and t[1].args[6] == _lib._float_bits(0.9)
+    assert c['patches'] == [(1, 5, lrt)]
+    assert t[2].args[7] == 0xFFFFFFFFFFFFFFFF                      # padding_idx = -1, two's complement
+    streams = (ctypes.c_void_p * 3)(None, None, None)
+    bad = (_lib.Launch * 1)()
+    bad[0].kind, bad[0].lane, bad[0].entry, bad[0].nargs = 0, 0, _lib.PLAN_ENTRIES['capmi_adam'], 3
+    assert L.capmi_plan_run(bad, 1, streams, 3) != 0 and 'capmi_adam takes 11' in _lib.last_error()
+    bad[0].lane = 5
+    assert L.capmi_plan_run(bad, 1, streams, 3) != 0 and 'lane 5' in _lib.last_error()
+    bad[0].lane, bad[0].kind = 0, 9
+    assert L.capmi_plan_run(bad, 1, streams, 3) != 0 and 'kind 9' in _lib.last_error()
+    assert L.capmi_plan_run(bad, 0, streams, 3) == 0
 
 
 def test_argument_errors_are_reported_not_thrown():
@@ -301,3 +338,116 @@ def test_device_feeder_keeps_the_reader_contract():
     f.close()
     f.worker.join(timeout=5)
     assert not f.worker.is_alive()
+
+
+# ------------------------------------------------------------------ LR schedule state + checkpoint resume (host logic, CPU)
+def _stateful_reference_lr(strategy, base_lr, spe, steps, decay_epoch, warmup_epoch, max_epoch):
+    """Run-by-run simulation of the reference's graph ops (tools/util.py:47-119) with their persistable state:
+    `@LR_DECAY_COUNTER@` incremented inside every run, `cur_epoch` += 1 when counter % spe == 0."""
+    import math
+    begin = 1 if strategy in ('cosine_decay_warmup', 'cosine_decay_restart_warmup') else 0
+    counter, cur_epoch_var, out = begin - 1, 0.0, []
+
+    def restart(cf, t_mul=2.0):
+        i = math.floor(math.log(1.0 - cf * (1.0 - t_mul)) / math.log(t_mul))
+        return (cf - (1.0 - t_mul ** i) / (1.0 - t_mul)) / t_mul ** i
+    for _ in range(steps):
+        counter += 1
+        g = float(counter)
+        if strategy == 'cosine_decay':
+            lr = base_lr * 0.5 * (math.cos(math.floor(g / spe) * math.pi / decay_epoch) + 1)
+        elif strategy == 'cosine_decay_warmup':
+            ce = math.floor(g / spe)
+            lr = 1e-5 + (base_lr - 1e-5) / warmup_epoch * ce if ce < warmup_epoch else \
+                0.5 * base_lr * (math.cos((ce - warmup_epoch) * math.pi / float(max_epoch - warmup_epoch)) + 1)
+        elif strategy == 'cosine_decay_restart':
+            lr = base_lr * 0.5 * (math.cos(math.pi * restart(math.floor(g / spe) / decay_epoch)) + 1)
+        else:
+            if counter % spe <= 0:
+                cur_epoch_var += 1
+            lr = 1e-5 + (base_lr - 1e-5) * (cur_epoch_var / float(warmup_epoch)) if cur_epoch_var < warmup_epoch else \
+                base_lr * 0.5 * (math.cos(math.pi * restart((cur_epoch_var - warmup_epoch) / decay_epoch)) + 1)
+        out.append(lr)
+    return out, counter, cur_epoch_var
+
+
+@pytest.mark.parametrize('strategy', ['cosine_decay', 'cosine_decay_warmup', 'cosine_decay_restart', 'cosine_decay_restart_warmup'])
+def test_lr_value_is_a_pure_function_of_the_step(strategy):
+    from myimagecaptioningmodel_amd.optim import LRSchedule
+    spe, steps = 7, 80
+    s = LRSchedule(strategy, 1e-3, 70, 10, decay_epoch=3, warmup_epoch=2, max_epoch=10)
+    assert s.step_each_epoch == spe
+    want, counter, cur_epoch = _stateful_reference_lr(strategy, 1e-3, spe, steps, 3, 2, 10)
+    got_fwd = [s.value(i) for i in range(steps)]
+    got_rev = [s.value(i) for i in reversed(range(steps))][::-1]        # any order, any number of calls
+    assert got_fwd == got_rev == [s.value(i) for i in range(steps)]
+    np.testing.assert_allclose(got_fwd, want, rtol=1e-12)
+    assert s.counter_after(steps) == counter and s.steps_from_counter(counter) == steps
+    if strategy == 'cosine_decay_restart_warmup':
+        assert s.cur_epoch_after(steps) == cur_epoch
+
+
+class _HostEngine:
+    """What ckpt.save_persistables / load_persistables touch of an engine, over a CPU ParamStore."""
+
+    def __init__(self, cfg, seed):
+        from myimagecaptioningmodel_amd.optim import LRSchedule
+        from myimagecaptioningmodel_amd.params import ParamStore
+        self.cfg = cfg
+        self.store = ParamStore(cfg, 'cpu')
+        self.store.init_reference(seed)
+        self.step_count = 0
+        self.lr_schedule = LRSchedule(cfg.get('lr_decay_strategy'), 1e-3, cfg.get('sample_count', 0), cfg.get('batch_size', 1),
+                                      cfg.get('decay_epoch', 0), cfg.get('warmup_epoch', 3), cfg.get('max_epoch', 10))
+
+    def export_reference_params(self):
+        return self.store.export_reference()
+
+    def load_reference_params(self, params):
+        self.store.load_reference(params)
+
+
+@pytest.mark.parametrize('steps', [0, 5, 1000, 22149])
+@pytest.mark.parametrize('strategy', [None, 'cosine_decay_restart_warmup'])
+def test_checkpoint_round_trip_restores_step_moments_and_counters(tmp_path, steps, strategy):
+    """the step count used to be recovered from float32 0.9^(t+1), which is 0 from t ~ 980."""
+    import torch
+    from myimagecaptioningmodel_amd import ckpt
+    from myimagecaptioningmodel_amd.config_compat import default_cfg
+    cfg = default_cfg(encoder='mobilenetv2', image_size=64, hidden=16, embed=8, vocab=20, sentence_length=5, infer_max_length=5,
+                      lr_decay_strategy=strategy, decay_epoch=2, warmup_epoch=1, sample_count=70, batch_size=10)
+    a, b = _HostEngine(cfg, 0), _HostEngine(cfg, 1)
+    g = torch.Generator().manual_seed(3)
+    a.store.adam_m.copy_(torch.randn(a.store.size, generator=g))
+    a.store.adam_v.copy_(torch.rand(a.store.size, generator=g))
+    for t in a.store.state.values():
+        t.copy_(torch.rand(t.shape, generator=g) + 0.5)
+    a.step_count = steps
+    d = str(tmp_path / 'checkpoint')
+    ckpt.save_persistables(a, d)
+    assert os.path.isfile(os.path.join(d, '@LR_DECAY_COUNTER@')) and os.path.isfile(os.path.join(d, 'lstm_w_moment1_0'))
+    assert os.path.isfile(os.path.join(d, 'cur_epoch')) == (strategy is not None)
+    ckpt.load_persistables(b, d)
+    assert b.step_count == steps
+    for buf in ('flat', 'adam_m', 'adam_v'):       # compared in the reference layout (the flat buffers have alignment gaps)
+        x, y = a.store.export_reference(getattr(a.store, buf)), b.store.export_reference(getattr(b.store, buf))
+        assert all(np.array_equal(x[k], y[k]) for k in a.store.entries), buf
+    for k in a.store.state:
+        assert torch.equal(a.store.state[k], b.store.state[k])
+    assert b.lr_schedule.value(b.step_count) == a.lr_schedule.value(steps)
+    # a reference checkpoint trained without a decay strategy has no counter file: beta2_pow_acc in float64
+    os.remove(os.path.join(d, '@LR_DECAY_COUNTER@'))
+    c = _HostEngine(cfg, 2)
+    ckpt.load_persistables(c, d)
+    assert abs(c.step_count - steps) <= max(0, int(steps * 6e-5)) and (steps > 1700 or c.step_count == steps)
+    # params-only export (train.py:78-79) and the pretrained-encoder predicate load (train.py:97-99)
+    ckpt.save_params(a, str(tmp_path / 'params'))
+    assert not os.path.exists(str(tmp_path / 'params' / 'lstm_w_moment1_0'))
+    e = _HostEngine(cfg, 4)
+    enc_only = str(tmp_path / 'pretrained')
+    os.makedirs(enc_only)
+    for n in ('conv1_1_weights', 'conv9_weights'):
+        os.link(str(tmp_path / 'params' / n), os.path.join(enc_only, n))
+    assert sorted(ckpt.load_vars_existing(e, enc_only)) == ['conv1_1_weights', 'conv9_weights']
+    assert torch.equal(e.store.view('conv9_weights'), a.store.view('conv9_weights'))
+    assert not torch.equal(e.store.view('lstm_w'), a.store.view('lstm_w'))

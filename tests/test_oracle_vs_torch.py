@@ -36,13 +36,40 @@ def test_oracle_matches_torch_autograd(tiny_cfg, attention, encoder):
     tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=om.is_trainable(k, cfg)) for k, v in params.items()}
     tl, tlogits = torch_ref.forward_loss(cfg, tp, torch.tensor(image), torch.tensor(caption))
     tl.backward()
-    assert abs(float(tl) - float(loss)) <= 1e-10 * max(1.0, abs(float(tl)))
+    assert abs(float(tl.detach()) - float(loss)) <= 1e-10 * max(1.0, abs(float(tl.detach())))
     np.testing.assert_allclose(logits, tlogits.detach().numpy(), rtol=1e-9, atol=1e-9)
     for k, g in grads.items():
         tg = tp[k].grad
         tg = np.zeros_like(g) if tg is None else tg.numpy()
         scale = max(1e-12, np.abs(tg).max())
         assert np.abs(g - tg).max() <= 1e-8 * scale + 1e-12, k
+
+
+@pytest.mark.parametrize('attention', ['singleton', 'slots'])
+def test_two_layer_lstm_oracle_matches_torch_autograd(tiny_cfg, attention):
+    """BASELINE configs[3]'s stacked decoder (build-defined: the reference stores rnn_layer and never reads it)."""
+    cfg = dict(tiny_cfg, attention=attention, rnn_layer=2)
+    params, image, caption = _setup(cfg, seed=4)
+    assert params['lstm_w_l1'].shape == (2 * cfg['hidden'], 4 * cfg['hidden'])
+    m = om.OracleModel(cfg, {k: v.copy() for k, v in params.items()})
+    loss, logits = m.forward_train(image, caption)
+    grads = m.backward()
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=om.is_trainable(k, cfg)) for k, v in params.items()}
+    tl, tlogits = torch_ref.forward_loss(cfg, tp, torch.tensor(image), torch.tensor(caption))
+    tl.backward()
+    assert abs(float(tl.detach()) - float(loss)) <= 1e-10 * max(1.0, abs(float(tl.detach())))
+    np.testing.assert_allclose(logits, tlogits.detach().numpy(), rtol=1e-9, atol=1e-9)
+    for k, g in grads.items():
+        tg = tp[k].grad
+        tg = np.zeros_like(g) if tg is None else tg.numpy()
+        assert np.abs(g - tg).max() <= 1e-8 * max(1e-12, np.abs(tg).max()) + 1e-12, k
+    assert np.abs(grads['lstm_w_l1']).max() > 0 and np.abs(grads['lstm_b_l1']).max() > 0
+    # the stacked decode loops: beam = 1 is the greedy loop, and one layer of the stack with an identity-free check:
+    ids, _ = m.greedy_decode(image, update_stats=False)
+    ids1, score, _ = m.beam_decode(image, 1, update_stats=False)
+    assert np.array_equal(ids, ids1) and ids.shape == (image.shape[0], cfg['infer_max_length'])
+    ids3, score3, _ = m.beam_decode(image, 3, update_stats=False)
+    assert np.all(score3 >= score - 1e-12)
 
 
 def test_finite_differences(tiny_cfg):

@@ -45,8 +45,9 @@ def forward_loss(cfg, params, image, caption):
     Vt = torch.tanh(fc(om.FC_IMG_FEAT, V0))
     Ve = fc(om.FC_IMG_FEAT_EMB, V0)
     H = cfg['hidden']
-    hid = torch.zeros(B, H, dtype=feat.dtype)
-    cell = torch.zeros(B, H, dtype=feat.dtype)
+    nl = cfg.get('rnn_layer', 1)
+    hids = [torch.zeros(B, H, dtype=feat.dtype) for _ in range(nl)]
+    cells = [torch.zeros(B, H, dtype=feat.dtype) for _ in range(nl)]
     target = caption[:, 1:]
     source = caption[:, :-1]
     mask = (target != cfg['padding_idx']).to(feat.dtype)
@@ -56,13 +57,18 @@ def forward_loss(cfg, params, image, caption):
         w = source[:, s]
         emb = emb_table[w] * (w != cfg['padding_idx']).to(feat.dtype)[:, None]
         xt = torch.cat([emb, g], -1)
-        gates = torch.cat([xt, hid], -1) @ p['lstm_w'] + p['lstm_b']
-        i, f, o, gg = gates.split(H, dim=-1)
-        c = torch.sigmoid(f) * cell + torch.sigmoid(i) * torch.tanh(gg)
-        h = torch.sigmoid(o) * torch.tanh(c)
+        hid = hids[-1]                      # the sentinel gate reads the top layer's previous hidden state
+        xin = xt
+        for l in range(nl):                 # stacked lstm_unit layers (build-defined for l >= 1)
+            wn, bn = om.lstm_names(l)
+            gates = torch.cat([xin, hids[l]], -1) @ p[wn] + p[bn]
+            i, f, o, gg = gates.split(H, dim=-1)
+            c = torch.sigmoid(f) * cells[l] + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            hids[l], cells[l] = h, c
+            xin = h
         sg = torch.sigmoid(fc(om.FC_P_WORD, xt) + fc(om.FC_P_HIDDEN, hid))
         sentinel = sg * torch.tanh(c)
-        hid, cell = h, c
         p_hid = torch.tanh(fc(om.FC_P_HID, h))
         hid_emb = fc(om.FC_HID_EMB, p_hid)
         sent_emb = fc(om.FC_SENT_EMB, sentinel)
