@@ -47,16 +47,22 @@ def synthetic_batch(B, cfg, seed):
 
 
 def pmc_traffic(label):
-    """HBM bytes per launch of `label` from the committed PMC passes (profiles/r*_pmc_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read inside this process, so
-    the value is the one measured for the same command when the profile was taken; None if absent."""
+    """HBM bytes per launch of `label` from the newest committed PMC pass (profiles/rNN_pmc_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC
+    counters cannot be read inside this process, so the value comes from a SEPARATE profile pass of the same command;
+    returns (MB per launch or None, source) -- source names the file and the tree it was recorded on, and the value is
+    None when the kernel symbol is missing or matched by more than one row (a renamed or re-tiled kernel)."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')))
+    files = glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json'))
+    rnd = lambda f: int(re.match(r'r(\d+)_', os.path.basename(f)).group(1))
+    files = sorted((f for f in files if re.match(r'r\d+_', os.path.basename(f))), key=rnd)
     if not files:
-        return None
-    kernels = json.load(open(files[-1]))['kernels']
+        return None, None
+    with open(files[-1]) as fh:
+        doc = json.load(fh)
+    kernels = doc['kernels']
+    source = dict(file=os.path.relpath(files[-1], ROOT), recorded_on=doc.get('head'), pass_='separate rocprofv3 --pmc runs of bench.py')
     m = re.match(r'(igemm_(nt|tn)_kernel)<(bf16|f32),(\d+),(\d+)>', label)
     g = re.match(r'igemm_nt_glds_kernel<(\d+),(\d+)>', label)
     if m:
@@ -66,38 +72,197 @@ def pmc_traffic(label):
         hit = [v for k, v in kernels.items() if ('igemm_nt_glds_kernel<%s, %s,' % (g.group(1), g.group(2))) in k
                or k.startswith('_Z20igemm_nt_glds_kernelILi%sELi%sE' % (g.group(1), g.group(2)))]
     else:
-        hit = [v for k, v in kernels.items() if label.replace('_kernel', '') in k]
-    return round(hit[0]['hbm_bytes_per_launch'] / 1e6, 3) if hit else None       # MB per launch
+        hit = [v for k, v in kernels.items() if re.search(r'\b%s\b' % re.escape(label), k)]
+    if len(hit) != 1:
+        return None, source
+    return round(hit[0]['hbm_bytes_per_launch'] / 1e6, 3), source
+
+
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box gives one GPU's
+    job a share of the host -- spinning more threads than the quota allows stalls the whole process every scheduler
+    period, DESIGN.md lesson 18).  When no quota can be read the share is taken to be 16 cores (what the pool grants a
+    one-GPU job); CAPMI_CPU_CORES overrides."""
+    if os.environ.get('CAPMI_CPU_CORES'):
+        return max(1, int(os.environ['CAPMI_CPU_CORES']))
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = None
+    rel = ''
+    try:
+        for line in open('/proc/self/cgroup'):
+            parts = line.strip().split(':', 2)
+            if len(parts) == 3 and (parts[1] == '' or 'cpu' in parts[1].split(',')):
+                rel = parts[2]
+    except Exception:
+        pass
+    cands = [('/sys/fs/cgroup' + rel + '/cpu.max', 2), ('/sys/fs/cgroup/cpu.max', 2),
+             ('/sys/fs/cgroup/cpu' + rel + '/cpu.cfs_quota_us', 1), ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', 1)]
+    for path, ver in cands:
+        try:
+            txt = open(path).read().split()
+            if ver == 2:
+                q = None if txt[0] == 'max' else float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                q = None if q <= 0 else q / float(open(os.path.join(os.path.dirname(path), 'cpu.cfs_period_us')).read())
+            if q:
+                quota = q
+            break
+        except Exception:
+            continue
+    if quota is None:
+        return max(1, min(n, 16))
+    return max(1, min(n, int(quota)))
+
+
+def progress(msg):
+    """One line on stderr per phase: a long run stays visibly alive (stdout carries only the JSON line)."""
+    sys.stderr.write('bench: %s\n' % msg)
+    sys.stderr.flush()
+
+
+def _cpu_train_steps(ocfg, B, warm, steps, seed, deadline):
+    """fwd + bwd (torch.autograd) + Paddle-form Adam of the reference graph on the host cores: tests/torch_ref.py, the
+    torch restatement that pins the NumPy oracle (same graph, same initialisers).  Returns (seconds per step, steps)."""
+    import torch
+    from oracle import model as om
+    from tests import torch_ref
+    params = om.init_params(ocfg, seed=0, dtype=np.float32)
+    p = {k: torch.tensor(v, requires_grad=om.is_trainable(k, ocfg)) for k, v in params.items()}
+    train = [v for v in p.values() if v.requires_grad]
+    m = [torch.zeros_like(v) for v in train]
+    v2 = [torch.zeros_like(v) for v in train]
+    image, cap = synthetic_batch(B, ocfg, seed)
+    image, cap = torch.tensor(image), torch.tensor(cap)
+    times = []
+    for it in range(warm + steps):
+        t0 = time.perf_counter()
+        loss, _ = torch_ref.forward_loss(ocfg, p, image, cap)
+        grads = torch.autograd.grad(loss, train, allow_unused=True)
+        t = it + 1
+        lr_t = 5e-5 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)            # IC/train.py:26-31: Paddle-1.8 adam op
+        with torch.no_grad():
+            for w, g, mm, vv in zip(train, grads, m, v2):
+                if g is None:
+                    continue
+                mm.mul_(0.9).add_(g, alpha=0.1)
+                vv.mul_(0.999).addcmul_(g, g, value=0.001)
+                w.sub_(lr_t * mm / (vv.sqrt() + 1e-8))
+        dt = time.perf_counter() - t0
+        if it >= warm:
+            times.append(dt)
+        if time.perf_counter() > deadline and len(times) >= 1:
+            break
+    return (sum(times) / len(times), len(times)) if times else (dt, 0)
 
 
 def cpu_baseline(cfg, budget_s=25.0):
-    """The NumPy oracle ('port' of the reference graph, not PaddlePaddle) timed on the host cores
-    on a bounded sample: whole train steps (fwd + bwd + Adam) of the SAME model at a small batch."""
+    """'build's CPU restatement of the reference graph, not PaddlePaddle' (Paddle 1.8 is not
+    installable here) = the torch-CPU build of the identical graph (tests/torch_ref.py), whole train steps (fwd + bwd +
+    Paddle-form Adam) in fp32 on the box's host cores, 2 warm-up + >= 5 timed steps: BASELINE cfg 1 (repo-default
+    MobileNetV2 model, 64x64, V 1000, L 10, B 4) and the bench workload (ResNet-50, 224x224, V 10000, L 20) at the
+    largest batch <= 64 whose 7 steps fit the budget.  `value` is the bench workload's rate."""
+    import torch
     from oracle import model as om
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    ocfg = om.default_cfg(**{k: cfg[k] for k in ('encoder', 'image_size', 'hidden', 'embed', 'vocab', 'sentence_length',
-                                                 'infer_max_length', 'attention')})
-    B = 2
-    params = om.init_params(ocfg, seed=0, dtype=np.float32)
-    m = om.OracleModel(ocfg, params)
-    image, cap = synthetic_batch(B, cfg, 1234)
-    t0 = time.time()
-    steps = 0
-    while True:
-        m.forward_train(image, cap)
-        g = m.backward()
-        m.adam_step(g, lr=cfg['learning_rate'])
-        steps += 1
-        if time.time() - t0 > budget_s or steps >= 3:
-            break
-    dt = time.time() - t0
-    return dict(value=round(B * steps / dt, 4), unit='images/sec', cores=int(cores), kind='port',
-                sample='%d train step(s) (fwd+bwd+Adam) of the same ResNet-50 captioning model at batch %d, fp32 NumPy oracle, %.1f s'
-                       % (steps, B, dt))
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    t_start = time.perf_counter()
+    progress('cpu baseline on %d core(s): cfg 1' % cores)
+    ocfg1 = om.default_cfg(encoder='mobilenetv2', image_size=64, hidden=1024, embed=256, vocab=1000, sentence_length=10,
+                           infer_max_length=10, attention='singleton')
+    s1, n1 = _cpu_train_steps(ocfg1, 4, 2, 5, 1234, t_start + 0.3 * budget_s)
+    ocfg2 = om.default_cfg(**{k: cfg[k] for k in ('encoder', 'image_size', 'hidden', 'embed', 'vocab', 'sentence_length',
+                                                  'infer_max_length', 'attention')})
+    # probe at batch 8, then the largest power-of-two batch <= 64 whose 2 + 5 steps fit what is left of the budget
+    progress('cpu baseline: cfg 1 %.3f s/step; probing the bench workload at batch 8' % s1)
+    probe, _ = _cpu_train_steps(ocfg2, 8, 1, 1, 1234, time.perf_counter() + 60.0)
+    left = budget_s - (time.perf_counter() - t_start)
+    B = 64
+    while B > 8 and 7 * probe * (B / 8.0) * 0.8 > left:        # (x0.8: larger batches run the cores more efficiently)
+        B //= 2
+    progress('cpu baseline: %.2f s/step at batch 8; timing batch %d' % (probe, B))
+    s2, n2 = _cpu_train_steps(ocfg2, B, 2, 5, 1234, time.perf_counter() + max(left, 5.0) * 1.5)
+    return dict(value=round(B / s2, 3), unit='images/sec', cores=int(cores), kind='port',
+                sample='torch-CPU fp32 restatement of the reference graph (tests/torch_ref.py: fwd + autograd bwd + Paddle-form Adam), '
+                       'NOT PaddlePaddle; bench workload (ResNet-50, 224x224, V 10000, L 20) at batch %d: %d timed steps after 2 warm-up, '
+                       '%.2f s/step; %.1f s of CPU work in all' % (B, n2, s2, time.perf_counter() - t_start),
+                cfg1=dict(value=round(4 / s1, 2), unit='images/sec', sample='BASELINE cfg 1 (repo-default MobileNetV2 + 1024/256 decoder, 64x64, '
+                          'V 1000, L 10, batch 4, singleton attention): %d timed steps after 2 warm-up, %.3f s/step' % (n1, s1)))
+
+
+def extras(eng, cfg, B, image_d, cap_d, dev, steps=10):
+    """Extra lines next to the headline (same workload, same batch, same weights): the reference-faithful attention
+    (quirk Q1, softmax over a size-1 axis: 'singleton'), the reference precision (f32 end to end), and the loss gap of the
+    bf16 engine against the f32 engine on the first step."""
+    import torch
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+    res = {}
+
+    def rate(e, n):
+        for _ in range(3):
+            e.train_step(image_d, cap_d)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            e.train_step(image_d, cap_d)
+        torch.cuda.synchronize()
+        return round(B * n / (time.perf_counter() - t0), 1)
+    first = {}
+    for key, over in (('bf16_slots', {}), ('bf16_singleton_attention', dict(attention='singleton')), ('f32_slots', dict(dtype='f32'))):
+        progress('extra: ' + key)
+        e = CaptionEngine(dict(cfg, **over), device=dev, use_graph=False)      # every engine starts from the same seeded initialisation
+        first[key] = float(e.forward_loss(image_d, cap_d).cpu()[0])
+        if key != 'bf16_slots':
+            res[key + '_images_per_sec'] = rate(e, steps if key != 'f32_slots' else max(3, steps // 2))
+        del e
+        torch.cuda.empty_cache()
+    res['first_step_loss'] = {k: round(v, 5) for k, v in first.items()}
+    res['loss_gap_bf16_vs_f32_engine'] = round(abs(first['bf16_slots'] - first['f32_slots']), 5)
+    res['note'] = ('singleton = the reference graph as written (alpha == 1); f32 = reference precision (exact-f32 MFMA kernels); losses and the '
+                   'gap are taken at the seeded initialisation, engine against engine at full size -- against the CPU oracle the tests '
+                   'hold bf16 to 5e-2 and f32 to 1e-3')
+    return res
+
+
+def decode_bench(args):
+    """BASELINE configs[4] (`--decode`): the infer.py path (/root/reference/ImageCaptioning/infer.py:26-36 runs the saved
+    GREEDY graph on one image; beam search is this build's extension) at batch 128, beam 5, 224x224, ResNet-50 + 512-d
+    decoder, bf16, `is_test` batch norm as in the exported inference model.  One step = one batch decoded (encoder +
+    Ti = 20 decoder steps + backtrack), replayed from a hipGraph; prints captions/sec and the p50 latency of a batch."""
+    import torch
+    from myimagecaptioningmodel_amd import default_cfg
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+    B, beam = args.batch or 128, args.beam
+    cfg = default_cfg(batch_size=B, sample_count=0, **WORKLOAD)
+    eng = CaptionEngine(cfg, device='cuda:0', use_graph=not args.no_graph)
+    image, _ = synthetic_batch(B, cfg, 1234)
+    image_d = torch.as_tensor(image).to('cuda:0')
+    for _ in range(max(2, args.warmup)):          # call 1 warms up + captures, later calls replay
+        ids = eng.decode(image_d, beam=beam, is_test=True)
+    torch.cuda.synchronize()
+    lat = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        ids = eng.decode(image_d, beam=beam, is_test=True)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    dt = time.perf_counter() - t0
+    ids = ids.cpu().numpy()
+    assert ids.shape == (B, cfg['infer_max_length']) and ((ids >= 0) & (ids < cfg['vocab'])).all()
+    lat.sort()
+    out = {'metric': 'decode captions/sec (224x224, beam=%d, batch %d)' % (beam, B), 'value': round(B * args.steps / dt, 1), 'unit': 'captions/sec',
+           'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+           'p50_latency_ms': round(lat[len(lat) // 2] * 1e3, 3), 'p90_latency_ms': round(lat[int(len(lat) * 0.9)] * 1e3, 3),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+           'config': {'workload': 'BASELINE configs[4]: infer.py path, ResNet-50 (build-defined) + 512-d decoder, vocab 10000, 224x224, '
+                                  'Ti 20, beam %d (build-defined; beam 1 = the reference greedy loop), is_test batch norm, random-init weights' % beam,
+                      'batch': B, 'beam': beam, 'launch': 'hipGraph replay of a single-lane plan' if not args.no_graph else 'capmi_plan_run, eager'}}
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -105,7 +270,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=PER_GPU_BATCH, help='per-GPU batch (default: the BASELINE config)')
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: the BASELINE config: 64 train, 128 decode)')
+    ap.add_argument('--decode', action='store_true', help='BASELINE configs[4]: beam-search decode captions/sec + p50 latency (extra mode)')
+    ap.add_argument('--beam', type=int, default=5)
+    ap.add_argument('--no-extras', action='store_true', help='skip the extra lines (singleton attention, f32, loss gap)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -117,6 +285,9 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    if args.decode:
+        os.dup2(real_stdout, 1)
+        return decode_bench(args)
     import torch
     import torch.distributed as dist
     from myimagecaptioningmodel_amd import default_cfg, dp, profiling
@@ -127,7 +298,7 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
     dev = 'cuda:%d' % local
     torch.cuda.set_device(local)
-    B = args.batch
+    B = args.batch or PER_GPU_BATCH
     cfg = default_cfg(batch_size=B * world, sample_count=0, **WORKLOAD)
     eng = CaptionEngine(cfg, device=dev, use_graph=not args.no_graph, process_group=pg)
     trainer = dp.OverlappedTrainer(eng) if pg is not None else None      # (CAPMI_FORCE_DP=1: the N > 1 path on one rank)
@@ -140,6 +311,7 @@ def main():
             return trainer.train_step(image_d, cap_d)
         return eng.train_step(image_d, cap_d)
 
+    progress('engine built; warm-up')
     for _ in range(max(1, args.warmup)):      # >= 1: builds plans, captures the hipGraph
         loss, _ = step()
     torch.cuda.synchronize()
@@ -171,11 +343,18 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: ResNet-50 (build-defined) + 512-d adaptive-attention LSTM decoder, '
                                    'vocab 10000, 224x224, seq_len 20, E=H=512, attention=slots, random-init weights',
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
-                       'hipgraph': not args.no_graph},
+                       # what ran in the timed region: laned plans are enqueued eagerly through capmi_plan_run (one foreign
+                       # call per plan) on HIP streams; no hipGraph replays there (hipGraph serialises parallel branches)
+                       'hipgraph': False,
+                       'launch': ('capmi_plan_run: forward + backward + Adam as launch tables on 2 HIP streams' if trainer is None or not getattr(trainer, 'active', False)
+                                  else ('capmi_plan_run: one table per step on 3 HIP streams, gradient buckets through capmi_allreduce_bucket (RCCL)'
+                                        if trainer.native_comm is not None else 'per-bucket backward segments + torch.distributed all-reduce on a side stream')),
+                       'precision_note': 'bf16 storage / f32 accumulate: the bf16 engine is held to |loss - oracle| <= 5e-2 (tests); north_star\'s 1e-3 is met by the f32 engine'},
             'final_loss': round(final_loss, 4),
         }
     # ---- roofline of the dominant kernel: per-launch HIP-event timing of one eager step (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_roofline:
+        progress('%.2f ms/step; per-launch HIP-event pass for the roofline line' % (dt / args.steps * 1e3))
         prog = eng._train[B]
         stats = {}
         for plan in (prog['fwd'], prog['bwd']):
@@ -194,7 +373,8 @@ def main():
             achieved = s['bytes'] / (s['ms'] * 1e-3) / 1e9
             roof = dict(bound='hbm', achieved=round(achieved, 1), peak=profiling.PEAK_HBM_GBPS, unit='GB/s',
                         frac=round(achieved / profiling.PEAK_HBM_GBPS, 4))
-        roof.update(kernel=name, traffic=pmc_traffic(name), avg_launch_us=round(s['ms'] / s['launches'] * 1e3, 2),
+        traffic, traffic_src = pmc_traffic(name)
+        roof.update(kernel=name, traffic=traffic, traffic_source=traffic_src, avg_launch_us=round(s['ms'] / s['launches'] * 1e3, 2),
                     share_of_step=round(s['ms'] / total_ms, 3),
                     traffic_unit='MB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)',
                     algorithmic_per_launch={'GFLOP': round(s['flops'] / s['launches'] / 1e9, 3),
@@ -203,6 +383,8 @@ def main():
         out['kernel_breakdown_ms_per_step'] = {k: round(v['ms'] / 2, 3) for k, v in top[:8]}
         flops_img = 26.18e9          # 6 x 4.363 GMAC fwd, GEMM-class ops only
         out['model_mfma_frac'] = round(out['value'] * flops_img / (world * profiling.PEAK_MFMA_TFLOPS['bf16'] * 1e12), 4)
+    if rank == 0 and world == 1 and not args.no_extras:
+        out['extra'] = extras(eng, cfg, B, image_d, cap_d, dev)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(cfg)
     if rank == 0:

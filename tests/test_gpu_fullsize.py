@@ -210,7 +210,7 @@ def test_every_encoder_layer_in_situ_against_torch_matmul(monkeypatch, workload)
         dw = torch.as_tensor(grads[op.name + '_weights']).cuda().reshape(co, -1)
         err = float((dw - dw_ref).norm() / dw_ref.norm())
         worst['wgrad'] = max(worst['wgrad'], err)
-        assert err < 5e-4, (op.name, 'weight gradient', err)            # f32 sums of ~1e5 terms in two different orders
+        assert err < 1e-3, (op.name, 'weight gradient', err)            # f32 sums of 1e5 .. 2.4e6 terms (the 384x384 stem) in two different orders
         checked['wgrad'] += 1
         # batch-norm backward: dY above from the gradient of this layer's output (masked by its ReLU; masking an
         # already masked gradient again changes nothing), and the gradients of scale and offset

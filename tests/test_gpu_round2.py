@@ -276,6 +276,7 @@ def test_plan_runner_equals_the_per_launch_host_walk(encoder, dtype, monkeypatch
         monkeypatch.setenv('CAPMI_PY_PLAN', '1' if mode.startswith('py') else '0')
         monkeypatch.setenv('CAPMI_LANES', '0' if mode.endswith('1') else '1')
         eng = _engine(ecfg, params)
+        ids = eng.decode(image, is_test=True).cpu().numpy().copy()   # a single-lane plan on the untouched parameters (nothing updated)
         losses = []
         for _ in range(2):
             loss, lr = eng.train_step(image, caption)
@@ -285,7 +286,6 @@ def test_plan_runner_equals_the_per_launch_host_walk(encoder, dtype, monkeypatch
         out[mode] = dict(loss=[float(l.cpu()[0]) for l in losses], logits=prog['dec'].logits.clone(),
                          stats={k: v['mean'].clone() for k, v in prog['enc'].bn.items()},
                          params=eng.export_reference_params(), grads=eng.export_reference_grads(), lr=lr)
-        ids = eng.decode(image).cpu().numpy()          # a single-lane plan (replayed eagerly here: use_graph=False)
         out[mode]['ids'] = ids
     ref = out['py']
     assert ref['loss'][1] < ref['loss'][0]

@@ -8,14 +8,20 @@ tag="${1:-r01}"
 out="gpurun_out/prof_$tag"
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$out/bench_under_rocprof.json" 2> "$out/stats.err"
 cp "$(ls $out/stats/*/*kernel_stats.csv | head -1)" "$out/${tag}_bench_kernel_stats.csv"
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > "$out/bench_trace.json" 2> "$out/trace.err"
-python3 tools/trace_by_shape.py "$out/trace" > "$out/${tag}_kernel_time_by_shape.txt"
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out/trace" -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-roofline > "$out/bench_trace.json" 2> "$out/trace.err"
+python3 tools/trace_by_shape.py "$out/trace" 13 > "$out/${tag}_kernel_time_by_shape.txt"      # 10 timed + 3 warm-up steps: per-step columns
 python3 tools/trace_overlap.py "$out/trace" > "$out/${tag}_timeline_two_streams.txt"
 python3 tools/trace_by_queue.py "$out/trace" > "$out/${tag}_kernel_time_by_queue.txt"
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.err"
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-roofline > "$out/pmc_write.json" 2> "$out/pmc_write.err"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-extras --no-roofline > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.err"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-extras --no-roofline > "$out/pmc_write.json" 2> "$out/pmc_write.err"
 python3 tools/pmc_summary.py "$out/pmc_fetch" "$out/pmc_write" "$out/${tag}_pmc_traffic.json" "3 steps, two lanes"
+# MFMA busy per kernel, normalisation validated on the register-only MFMA loop of tools/peaks (tools/pmc_mfma.py)
+hipcc --offload-arch=gfx950 -O3 tools/peaks.hip -o tools/peaks
+timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_cal" -- tools/peaks > "$out/peaks.txt" 2> "$out/pmc_cal.err"
+timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_mfma" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-extras --no-roofline > "$out/pmc_mfma.json" 2> "$out/pmc_mfma.err"
+python3 tools/pmc_mfma.py "$out/pmc_cal" "$out/pmc_mfma" "$out/${tag}_pmc_mfma_busy.txt" 3
+rm -rf "$out/pmc_cal" "$out/pmc_mfma"
 rm -rf "$out/stats" "$out/trace" "$out/pmc_fetch" "$out/pmc_write"
 ls -la "$out"
