@@ -241,6 +241,26 @@ int capmi_lstm_step_fwd(const void* h_prev, const void* wh, int ldw, void* gates
 int capmi_lstm_step_bwd(const void* dgates_t, const void* whT, int ldwT, const void* dh_in, const void* gates_prev,
                         const void* c_prev, const void* c, const void* dc_in, void* dgates_prev, void* dc_prev,
                         int dc_prev_accumulate, int B, int H, int dtype, void* stream);
+/* The whole recurrence of ONE LSTM layer in one launch per direction (the While loop of model_adaAttention_aic.py:75-127
+ * reduced to its only sequential part, `lstm_unit` :87-88): the grid of the fused step kernels stays resident for all
+ * T steps, every wave keeps its slice of the recurrent weights in registers, and the steps are separated by a grid
+ * barrier (write-through hand-off + one agent-scope arrival counter) instead of 2T kernel boundaries.  Results equal
+ * the per-step launches up to FMA contraction in the cell (same k-split, MFMA order and rounding points).
+ *   fwd: hbuf / cbuf hold T+1 row blocks [B][H]; block 0 is the initial state (zeros, :63), blocks 1..T are written;
+ *        gates [T][B][4H] in: x_t.Wx^T + b, out: the full pre-activations.  wh: the recurrent columns of lstm_w,
+ *        [4H] rows of stride ldw.
+ *   bwd: gates / cbuf as fwd left them; dhbuf blocks 1..T = d loss / d h_t from everything except the recurrence (read
+ *        only); dcbuf blocks 1..T = d loss / d c_t from outside when dc_outside != 0 (the cell's own d c_{t-1} is then
+ *        added into block t-1), scratch otherwise; whT: [H] rows of stride ldwT (reduction over the 4H gates);
+ *        writes dgates [T][B][4H].
+ * sync: 16 bytes of device memory owned by the caller, zeroed by the call; word 1 != 0 after the launch means a grid
+ * barrier gave up waiting (bounded spin: the launch always drains) and the results are invalid.
+ * capmi_lstm_seq_supported: B <= 64 and H in {256, 384, 512, 768, 1024} (bf16) / H = 256 (f32). */
+int capmi_lstm_seq_supported(int B, int H, int T, int dtype);
+int capmi_lstm_seq_fwd(void* hbuf, const void* wh, int ldw, void* gates, void* cbuf, int B, int H, int T, void* sync,
+                       int dtype, void* stream);
+int capmi_lstm_seq_bwd(const void* gates, const void* cbuf, const void* whT, int ldwT, const void* dhbuf, void* dcbuf,
+                       void* dgates, int dc_outside, int B, int H, int T, void* sync, int dtype, void* stream);
 /* visual sentinel (:91-92): s = sigmoid(sgpre) * tanh(c); bwd -> dsgpre, dc. */
 int capmi_sentinel_fwd(const void* sgpre, const void* c, void* s, int64_t n, int dtype, void* stream);
 int capmi_sentinel_bwd(const void* ds, const void* sgpre, const void* c, void* dsgpre, void* dc,

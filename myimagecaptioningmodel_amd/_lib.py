@@ -71,6 +71,8 @@ SIGNATURES = {
     'capmi_lstm_cell_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_lstm_step_fwd': [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     'capmi_lstm_step_bwd': [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_lstm_seq_fwd': [_p, _p, _i, _p, _p, _i, _i, _i, _p, _i, _p],
+    'capmi_lstm_seq_bwd': [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p],
     'capmi_beam_step': [_p, _i, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'capmi_gather_rows': [_p, _p, _p, _i, _i, _i, _p],
     'capmi_beam_backtrack': [_p, _p, _p, _i, _i, _i, _p],
@@ -102,6 +104,7 @@ QUERIES = {
     'capmi_igemm_nt_bnred_part_rows': [_g, _i, _i],
     'capmi_bn_stats_part_rows': [_i, _i, _i],
     'capmi_lstm_step_supported': [_i, _i, _i],
+    'capmi_lstm_seq_supported': [_i, _i, _i, _i],
     'capmi_bn_bwd_ws_floats': [_i, _i, _i],
 }
 

@@ -8,6 +8,8 @@
 // v_mfma_f32_16x16x4_f32 (reference precision).  64-lane waves, 4 waves per workgroup in a 2x2
 // arrangement, register-staged double-buffered LDS tiles with 16-byte global loads; the output
 // tile goes back through LDS so that every global store is a full 16-byte chunk of a row.
+#include <stdlib.h>
+
 #include "common.h"
 
 // floor(n / d) as (n * ceil(2^40 / d)) >> 40, exact whenever n * d < 2^40 (checked by the launchers):
@@ -1148,6 +1150,362 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const T* __restrict_
         for (int g = 0; g < 4; ++g) *reinterpret_cast<Pair*>(dg_p + ge + g * H) = odg[g];
         if (dc_prev) *reinterpret_cast<Pair*>(dc_prev + e) = odc;
     }
+}
+
+// ------------------------------------------------------------------ the whole recurrence of one LSTM layer in ONE launch
+// T dependent steps were 2T launches per direction on a nearly idle chip (10.9 us per forward step, 15 + 6 us per
+// backward step at B = 64, H = 512).  Here the grid stays resident for all T steps: every wave keeps its slice of the
+// recurrent weights in registers for the whole sequence, and the steps are separated by a grid barrier instead of a
+// kernel boundary.  Same k-split, MFMA order and rounding points as lstm_step_{fwd,bwd}_kernel, so the results equal
+// the per-step launches up to the contraction of a*b + c*d in the cell (forward: bit for bit in bf16).
+//
+// Hand-off between steps (cdna_hip_programming.md, Guideline 16; MI355X_MICROARCH.md, inter-workgroup visibility:
+// per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores).  The bytes one workgroup writes and
+// the others read -- h_t forward, dG_t backward -- are stored WRITE-THROUGH (sc1, 4 or 8 bytes per store) and loaded
+// with sc1 loads (16 bytes, L1 bypassed); every storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets
+// at its barrier, ONE lane adds to ONE arrival counter (agent scope) and polls it with sc1 loads until step *
+// workgroups have arrived; the other waves load behind the workgroup barrier that lane then joins.  No fence: a release
+// (buffer_wbl2) costs 2-6 us per step with freshly dirtied lines, an acquire (buffer_inv) 1.7 us -- measured 13-15 us
+// per step with them, against 10.9 for a kernel boundary.  `fences` != 0 adds them back (agent-scope release before the
+// arrival, acquire behind the poll; CAPMI_LSTM_SEQ=2).  Everything else a workgroup touches is either written before the
+// launch or written and re-read by the same thread.  Every handed-off row block is written exactly once per launch
+// before it is read.  Grids are <= 128 workgroups of 256 threads: always co-resident.  Every spin is bounded: after
+// SEQ_SPIN_LIMIT polls a workgroup sets sync[1] and runs on (later barriers see the flag and do not wait), so the launch
+// always drains; the host checks sync[1] (capmi_lstm_seq_* zero both words before the launch).
+constexpr unsigned SEQ_SPIN_LIMIT = 1u << 21;
+typedef unsigned int seq_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void seq_grid_barrier(unsigned* sync, unsigned target, int fences) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's (write-through) stores have left the chip's caches
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (fences) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (kept: ROCm 7.2 can drop the fence's own wait)
+        }
+        __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SEQ_SPIN_LIMIT || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (fences) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the invalidate has completed before the barrier opens
+        }
+    }
+    __syncthreads();
+}
+// 8 consecutive elements at byte offset `off` of the buffer, L1 bypassed
+__device__ __forceinline__ void load_frag_sc1(Frag<bf16>& f, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    const seq_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16);
+    f.v = __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void load_frag_sc1(Frag<float>& f, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    const seq_u32x4 ua = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 16), ub = __builtin_amdgcn_raw_buffer_load_b128(r, off + 16, 0, 16);
+    const f32x4 a = __builtin_bit_cast(f32x4, ua), b = __builtin_bit_cast(f32x4, ub);      // (whole vectors: a bit_cast of ONE element read element 0 every time)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f.v[i] = a[i]; f.v[4 + i] = b[i]; }
+}
+// two adjacent elements as ONE write-through store
+__device__ __forceinline__ void store_pair_sc1(bf16* p, float x, float y) {
+    const bf16 a = (bf16)x, b = (bf16)y;
+    const unsigned v = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_pair_sc1(float* p, float x, float y) {
+    const unsigned long long v = (unsigned long long)__builtin_bit_cast(unsigned, x) | ((unsigned long long)__builtin_bit_cast(unsigned, y) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// forward: blocks 1..T of hbuf / cbuf from block 0 (the zero state); gates [T][B][4H] in: input part + bias, out: the
+// full pre-activations BPTT reads back.  Workgroup = 8 hidden units x 4 gates x all rows, as lstm_step_fwd_kernel.
+template <typename T, int KS>                                   // KS = H / 128: k-steps of 32 per wave
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(T* hbuf, const T* __restrict__ wh, int ldw, T* gates, T* cbuf,
+                                                           int B, int H, int Tn, unsigned* sync, int fences) {
+    __shared__ __attribute__((aligned(16))) float red[4][8][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int u0 = blockIdx.x * 8;
+    const int kbeg = wave * (H / 4);
+    Frag<T> wf[2][KS];                                          // this wave's recurrent weights, resident for the whole sequence
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cj = 2 * fr + j;
+        const T* row = wh + (int64_t)((cj >> 3) * H + u0 + (cj & 7)) * ldw + kbeg + fg * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[j][ks].load(row + ks * 32);
+    }
+    const __amdgpu_buffer_rsrc_t hres = __builtin_amdgcn_make_buffer_rsrc((void*)hbuf, 0, (unsigned)((size_t)(Tn + 1) * B * H * sizeof(T)), 0x00020000);
+    bool aok[4];
+    unsigned aoff[4];                                           // byte offsets inside one row block of hbuf
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = i * 16 + fr;
+        aok[i] = m < B;
+        aoff[i] = (unsigned)(((aok[i] ? m : 0) * H + kbeg + fg * 8) * sizeof(T));
+    }
+    const int b = tid & 63, up = (tid >> 6) * 2;                // the cell: row b, units u0 + up, u0 + up + 1
+    float* tile = &red[0][0][0][0];                             // [64][33]
+    const unsigned blk = (unsigned)((size_t)B * H * sizeof(T));
+    for (int t = 0; t < Tn; ++t) {
+        T* gt = gates + (int64_t)t * B * 4 * H;
+        T* cp = cbuf + (int64_t)t * B * H;
+        T* hn = hbuf + (int64_t)(t + 1) * B * H;
+        if (t > 0) {
+            seq_grid_barrier(sync, (unsigned)t * gridDim.x, fences);    // every workgroup has written its part of h_{t-1} (block t)
+            f32x4 acc[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                Frag<T> af[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    load_frag_sc1(af[i], hres, (unsigned)t * blk + aoff[i] + ks * 32 * (unsigned)sizeof(T));
+                    if (!aok[i]) af[i] = Frag<T>{};
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma16(acc[i][j], af[i], wf[j][ks]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&red[wave][i * 2 + j][lane][0]) = acc[i][j];
+            __syncthreads();
+            float v[4][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 sm = *reinterpret_cast<const f32x4*>(&red[0][wave * 2 + j][lane][0]);
+#pragma unroll
+                for (int w = 1; w < 4; ++w) sm += *reinterpret_cast<const f32x4*>(&red[w][wave * 2 + j][lane][0]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r][j] = sm[r];
+            }
+            __syncthreads();                                    // every wave has read the partial tiles
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) tile[(wave * 16 + fg * 4 + r) * 33 + 2 * fr + j] = v[r][j];
+            __syncthreads();
+        }
+        if (b < B) {
+            float hv[2];
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                const int u = up + uu;
+                T* gr = gt + (int64_t)b * 4 * H + u0 + u;
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (t > 0) {
+                        const T stored = from_f32<T>(tile[b * 33 + 8 * g + u] + to_f32(gr[g * H]));
+                        gr[g * H] = stored;                     // the pre-activation BPTT reads back
+                        pre[g] = to_f32(stored);
+                    } else {
+                        pre[g] = to_f32(gr[g * H]);             // h_{-1} = 0: the input part is the pre-activation
+                    }
+                }
+                float i_, f_, o_, g_, cn;
+                const float cpv = to_f32(cp[(int64_t)b * H + u0 + u]);
+                if (t > 0) {        // the arithmetic of lstm_step_fwd_kernel ...
+                    i_ = sigmoid_for<T>(pre[0]), f_ = sigmoid_for<T>(pre[1]), o_ = sigmoid_for<T>(pre[2]), g_ = tanh_for<T>(pre[3]);
+                    cn = f_ * cpv + i_ * g_;
+                    hv[uu] = o_ * tanh_for<T>(cn);
+                } else {            // ... and of capmi_lstm_cell_fwd, which runs step 0 of the per-step plan
+                    i_ = sigmoidf_(pre[0]), f_ = sigmoidf_(pre[1]), o_ = sigmoidf_(pre[2]), g_ = tanhf_(pre[3]);
+                    cn = f_ * cpv + i_ * g_;
+                    hv[uu] = o_ * tanhf_(cn);
+                }
+                cp[(int64_t)B * H + (int64_t)b * H + u0 + u] = from_f32<T>(cn);     // read back by this thread only
+            }
+            store_pair_sc1(hn + (int64_t)b * H + u0 + up, hv[0], hv[1]);            // read by every workgroup in step t + 1
+        }
+    }
+}
+
+// One cell backward on the thread's row x 2 units (the arithmetic of lstm_step_bwd_kernel; EXACT = the ocml functions
+// of capmi_lstm_cell_bwd, which runs the last time step of the per-step plan).  dG goes out write-through.
+template <typename T, bool EXACT>
+__device__ __forceinline__ void seq_cell_bwd(const float (&v)[2], bool have_product, const T* dh_in, const T* gates_p, const T* c_pp,
+                                             const T* c_p, const T* dc_in, T* dg_p, T* dc_prev, int dc_prev_acc, int H, int row, int col0) {
+    typedef T __attribute__((ext_vector_type(2))) Pair;
+    const int64_t e = (int64_t)row * H + col0, ge = (int64_t)row * 4 * H + col0;
+    Pair pg[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pg[g] = *reinterpret_cast<const Pair*>(gates_p + ge + g * H);
+    const Pair pc = *reinterpret_cast<const Pair*>(c_p + e);
+    const Pair pcp = c_pp ? *reinterpret_cast<const Pair*>(c_pp + e) : Pair{};
+    const Pair pdc = dc_in ? *reinterpret_cast<const Pair*>(dc_in + e) : Pair{};
+    const Pair pdh = *reinterpret_cast<const Pair*>(dh_in + e);
+    const Pair old_dc = (dc_prev && dc_prev_acc) ? *reinterpret_cast<const Pair*>(dc_prev + e) : Pair{};
+    float odg[4][2];
+    Pair odc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float dhh = have_product ? to_f32(from_f32<T>(v[j] + (float)pdh[j])) : (float)pdh[j];
+        float i_, f_, o_, g_, tc;
+        if constexpr (EXACT) {
+            i_ = sigmoidf_((float)pg[0][j]), f_ = sigmoidf_((float)pg[1][j]), o_ = sigmoidf_((float)pg[2][j]), g_ = tanhf_((float)pg[3][j]);
+            tc = tanhf_((float)pc[j]);
+        } else {
+            i_ = sigmoid_for<T>((float)pg[0][j]), f_ = sigmoid_for<T>((float)pg[1][j]), o_ = sigmoid_for<T>((float)pg[2][j]), g_ = tanh_for<T>((float)pg[3][j]);
+            tc = tanh_for<T>((float)pc[j]);
+        }
+        const float dct = (float)pdc[j] + dhh * o_ * (1.f - tc * tc);
+        const float cpv = (float)pcp[j];
+        odg[0][j] = dct * g_ * i_ * (1.f - i_);
+        odg[1][j] = dct * cpv * f_ * (1.f - f_);
+        odg[2][j] = dhh * tc * o_ * (1.f - o_);
+        odg[3][j] = dct * i_ * (1.f - g_ * g_);
+        odc[j] = from_f32<T>(dct * f_ + (float)old_dc[j]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) store_pair_sc1(dg_p + ge + g * H, odg[g][0], odg[g][1]);
+    if (dc_prev) *reinterpret_cast<Pair*>(dc_prev + e) = odc;
+}
+
+// backward (BPTT of one layer): gates / cbuf as the forward left them, dhbuf blocks 1..T = d loss / d h_t from everything
+// but the recurrence, dcbuf blocks 1..T = d loss / d c_t from outside (dc_outside != 0: the top layer, where the sentinel
+// reads c_t; the cell's own d c_{t-1} is then ADDED into block t-1; otherwise dcbuf is scratch the kernel writes).
+// Writes dgates [T][B][4H].  Workgroup = 16 rows x 32 hidden units (grid H/32 x ceil(B/16)): every workgroup reads only
+// its 16 rows of dG_t (64 KB at H = 512) per step, its waves split the 4H reduction four ways.  whT rows = hidden units.
+template <typename T, int KS, int NW>                           // NW waves split the 4H reduction; KS = 4H / NW / 32 k-steps per wave
+__global__ __launch_bounds__(64 * NW) void lstm_seq_bwd_kernel(const T* gates, const T* cbuf, const T* __restrict__ whT, int ldwT, const T* dhbuf,
+                                                           T* dcbuf, T* dgates, int dc_outside, int B, int H, int Tn, unsigned* sync, int fences) {
+    __shared__ __attribute__((aligned(16))) float red[NW][2][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 32, col0 = n0 + 2 * fr;
+    const int m0 = blockIdx.y * 16;
+    const int kbeg = wave * (4 * H / NW);
+    const unsigned nwg = gridDim.x * gridDim.y;
+    Frag<T> wf[2][KS];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const T* row = whT + (int64_t)(n0 + 2 * fr + j) * ldwT + kbeg + fg * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) wf[j][ks].load(row + ks * 32);
+    }
+    const __amdgpu_buffer_rsrc_t gres = __builtin_amdgcn_make_buffer_rsrc((void*)dgates, 0, (unsigned)((size_t)Tn * B * 4 * H * sizeof(T)), 0x00020000);
+    const bool aok = m0 + fr < B;
+    const unsigned aoff = (unsigned)(((aok ? m0 + fr : 0) * 4 * H + kbeg + fg * 8) * sizeof(T));
+    const unsigned blk = (unsigned)((size_t)B * 4 * H * sizeof(T));
+    const int row = m0 + fg * 4 + (wave & 3);                   // the cell (waves 0..3): this row, units col0, col0 + 1
+    const bool rok = row < B && wave < 4;
+    const int64_t BH = (int64_t)B * H;
+    float v[2] = {0.f, 0.f};
+    if (rok) {   // step T-1: no later step feeds it
+        const int t = Tn - 1;
+        seq_cell_bwd<T, true>(v, false, dhbuf + (t + 1) * BH, gates + t * 4 * BH, cbuf + t * BH, cbuf + (t + 1) * BH,
+                              dc_outside ? dcbuf + (t + 1) * BH : nullptr, dgates + t * 4 * BH, t > 0 ? dcbuf + t * BH : nullptr,
+                              dc_outside, H, row, col0);
+    }
+    for (int t = Tn - 1; t > 0; --t) {
+        seq_grid_barrier(sync, (unsigned)(Tn - t) * nwg, fences);       // every workgroup has written its part of dG_t
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            Frag<T> af;
+            load_frag_sc1(af, gres, (unsigned)t * blk + aoff + ks * 32 * (unsigned)sizeof(T));
+            if (!aok) af = Frag<T>{};
+            mma16(acc[0], af, wf[0][ks]);
+            mma16(acc[1], af, wf[1][ks]);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&red[wave][j][lane][0]) = acc[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float sm = red[0][j][lane][wave & 3];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sm += red[w][j][lane][wave & 3];
+            v[j] = sm;
+        }
+        // d h_{t-1} = its outside gradient (block t) + dG_t . Wh, then the cell backward of step t-1
+        if (rok)
+            seq_cell_bwd<T, false>(v, true, dhbuf + t * BH, gates + (t - 1) * 4 * BH, cbuf + (t - 1) * BH, cbuf + t * BH,
+                                   dcbuf + t * BH, dgates + (t - 1) * 4 * BH, t > 1 ? dcbuf + (t - 1) * BH : nullptr, dc_outside, H, row, col0);
+        // (red is rewritten only behind the next barrier's workgroup barrier)
+    }
+}
+
+extern "C" int capmi_lstm_seq_supported(int B, int H, int T, int dtype) {
+    if (B < 1 || B > 64 || T < 1) return 0;
+    if (dtype == CAPMI_BF16) return (H == 256 || H == 384 || H == 512 || H == 768 || H == 1024) ? 1 : 0;   // a wave's recurrent weights fit its registers
+    if (dtype == CAPMI_F32) return H == 256 ? 1 : 0;
+    return 0;
+}
+static int seq_sync_reset(void* sync, hipStream_t st, const char* who) {
+    hipError_t e = hipMemsetAsync(sync, 0, 16, st);
+    if (e != hipSuccess) {
+        capmi_set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
+        return 1;
+    }
+    return 0;
+}
+static int seq_fences() {      // CAPMI_LSTM_SEQ=2: agent-scope release / acquire fences around the arrival counter as well
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("CAPMI_LSTM_SEQ");
+        v = (e && e[0] == '2') ? 1 : 0;
+    }
+    return v;
+}
+extern "C" int capmi_lstm_seq_fwd(void* hbuf, const void* wh, int ldw, void* gates, void* cbuf, int B, int H, int T, void* sync, int dtype, void* stream) {
+    CAPMI_CHECK(hbuf && wh && gates && cbuf && sync, "capmi_lstm_seq_fwd: null pointer");
+    CAPMI_CHECK(capmi_lstm_seq_supported(B, H, T, dtype), "capmi_lstm_seq_fwd: B=%d H=%d T=%d dtype=%d outside the persistent kernel", B, H, T, dtype);
+    const int vec = dtype == CAPMI_F32 ? 4 : 8;
+    CAPMI_CHECK(ldw % vec == 0, "capmi_lstm_seq_fwd: ldw=%d must be a multiple of %d", ldw, vec);
+    CAPMI_CHECK((long long)(T + 1) * B * H * 4 < (1ll << 32), "capmi_lstm_seq_fwd: state buffer beyond 4 GiB");
+    hipStream_t st = (hipStream_t)stream;
+    if (seq_sync_reset(sync, st, "capmi_lstm_seq_fwd")) return 1;
+    const int fences = seq_fences();
+#define CAPMI_SEQ_FWD(TT, KS_) hipLaunchKernelGGL((lstm_seq_fwd_kernel<TT, KS_>), dim3(H / 8), dim3(256), 0, st, (TT*)hbuf, (const TT*)wh, ldw, (TT*)gates, (TT*)cbuf, B, H, T, (unsigned*)sync, fences)
+    if (dtype == CAPMI_BF16) {
+        if (H == 256) CAPMI_SEQ_FWD(bf16, 2);
+        else if (H == 384) CAPMI_SEQ_FWD(bf16, 3);
+        else if (H == 512) CAPMI_SEQ_FWD(bf16, 4);
+        else if (H == 768) CAPMI_SEQ_FWD(bf16, 6);
+        else CAPMI_SEQ_FWD(bf16, 8);
+    } else {
+        CAPMI_SEQ_FWD(float, 2);
+    }
+#undef CAPMI_SEQ_FWD
+    CAPMI_LAUNCH_CHECK("capmi_lstm_seq_fwd");
+    return 0;
+}
+extern "C" int capmi_lstm_seq_bwd(const void* gates, const void* cbuf, const void* whT, int ldwT, const void* dhbuf, void* dcbuf, void* dgates,
+                                  int dc_outside, int B, int H, int T, void* sync, int dtype, void* stream) {
+    CAPMI_CHECK(gates && cbuf && whT && dhbuf && dcbuf && dgates && sync, "capmi_lstm_seq_bwd: null pointer");
+    CAPMI_CHECK(capmi_lstm_seq_supported(B, H, T, dtype), "capmi_lstm_seq_bwd: B=%d H=%d T=%d dtype=%d outside the persistent kernel", B, H, T, dtype);
+    const int vec = dtype == CAPMI_F32 ? 4 : 8;
+    CAPMI_CHECK(ldwT % vec == 0, "capmi_lstm_seq_bwd: ldwT=%d must be a multiple of %d", ldwT, vec);
+    CAPMI_CHECK((long long)T * B * 4 * H * 4 < (1ll << 32), "capmi_lstm_seq_bwd: gate-gradient buffer beyond 4 GiB");
+    hipStream_t st = (hipStream_t)stream;
+    if (seq_sync_reset(sync, st, "capmi_lstm_seq_bwd")) return 1;
+    const int fences = seq_fences();
+    const dim3 grid(H / 32, (B + 15) / 16);
+#define CAPMI_SEQ_BWD(TT, KS_, NW_) hipLaunchKernelGGL((lstm_seq_bwd_kernel<TT, KS_, NW_>), grid, dim3(64 * NW_), 0, st, (const TT*)gates, (const TT*)cbuf, (const TT*)whT, ldwT, (const TT*)dhbuf, (TT*)dcbuf, (TT*)dgates, dc_outside, B, H, T, (unsigned*)sync, fences)
+    if (dtype == CAPMI_BF16) {
+        if (H == 256) CAPMI_SEQ_BWD(bf16, 8, 4);
+        else if (H == 384) CAPMI_SEQ_BWD(bf16, 12, 4);
+        else if (H == 512) CAPMI_SEQ_BWD(bf16, 16, 4);
+        else if (H == 768) CAPMI_SEQ_BWD(bf16, 12, 8);          // eight waves: a wave's weights stay within 128 registers
+        else CAPMI_SEQ_BWD(bf16, 16, 8);
+    } else {
+        CAPMI_SEQ_BWD(float, 8, 4);
+    }
+#undef CAPMI_SEQ_BWD
+    CAPMI_LAUNCH_CHECK("capmi_lstm_seq_bwd");
+    return 0;
 }
 
 extern "C" int capmi_lstm_step_supported(int B, int H, int dtype) {

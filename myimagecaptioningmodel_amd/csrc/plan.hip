@@ -85,6 +85,8 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_lstm_cell_bwd),
     CAPMI_ENTRY(capmi_lstm_step_fwd),
     CAPMI_ENTRY(capmi_lstm_step_bwd),
+    CAPMI_ENTRY(capmi_lstm_seq_fwd),
+    CAPMI_ENTRY(capmi_lstm_seq_bwd),
     CAPMI_ENTRY(capmi_sentinel_fwd),
     CAPMI_ENTRY(capmi_sentinel_bwd),
     CAPMI_ENTRY(capmi_ada_attention_fwd),

@@ -35,6 +35,7 @@ def vocab_ld(V):
 
 class DecoderRunner:
     fuse_lstm = True        # recurrent product + cell in one launch per step where capmi_lstm_step_supported
+    seq_lstm = True         # the whole recurrence of a layer in one launch per direction where capmi_lstm_seq_supported
 
     def __init__(self, store, B, K, T, dtype_code, torch_dtype, slots, need_backward=True):
         self.overlap_wgrad = True       # parameter-gradient launches of the backward plan go to the side lane
@@ -48,6 +49,11 @@ class DecoderRunner:
         self.slots = 1 if slots else 0
         self.pad = cfg['padding_idx']
         self.L = int(cfg.get('rnn_layer', 1))
+        # grid-barrier state of the persistent recurrence kernels: 16 bytes per launch (layer x direction); word 1 of a
+        # slot is set when a barrier gave up waiting (check_sync)
+        self.seq_sync = torch.zeros((2 * self.L, 4), dtype=torch.int32, device=store.device)
+        self.use_seq = (self.seq_lstm and os.environ.get('CAPMI_LSTM_SEQ', '1') != '0'
+                        and bool(lib().capmi_lstm_seq_supported(B, cfg['hidden'], T, dtype_code)))
         dev = store.device
         B, K, T, C, H, E, M = self.B, self.K, self.T, self.C, self.H, self.E, T * B
         z = lambda shape, dt=None: torch.zeros(shape, dtype=dt or self.tdt, device=dev)
@@ -86,6 +92,13 @@ class DecoderRunner:
             self.dHbuf, self.dCbuf, self.dG = self.dHbufs[-1], self.dCbufs[-1], self.dGs[0]
             self.dSGpre, self.dX = z((M, H)), z((M, E + H))
             self.dg, self.dV0, self.dAmean = z((B, H)), z((B * K, H)), z((B, C))
+
+    def check_sync(self):
+        """Raises if a grid barrier of the persistent recurrence kernels timed out in any launch so far (synchronises)."""
+        if bool(self.seq_sync[:, 1].any().item()):
+            from ._lib import CapmiError
+            raise CapmiError('capmi_lstm_seq: a grid barrier gave up waiting (sync words %s); the recurrence results are invalid'
+                             % self.seq_sync.cpu().tolist())
 
     # ------------------------------------------------------------------ tiny helpers
     def _gemm(self, plan, x, rows, K, w, N, y, ldw=None, ldx=None, ldy=None, bias=None, addend=None, ld_add=0,
@@ -196,6 +209,9 @@ class DecoderRunner:
             xin = _p(self.X) if l == 0 else _p(self.Hbufs[l - 1]) + off1
             self._gemm(plan, xin, M, kin, _p(lw), 4 * H, _p(G), ldw=ldl, bias=_p(st.view(bn)))
             wh = _p(lw) + kin * es
+            if self.use_seq:      # all T steps of the layer in one launch (grid barrier between steps)
+                plan.add('capmi_lstm_seq_fwd', _p(Hb), wh, ldl, _p(G), _p(Cb), B, H, T, self.seq_sync.data_ptr() + 32 * l, code)
+                continue
             fused = self.fuse_lstm and os.environ.get('CAPMI_LSTM_FUSE', '1') != '0' and bool(lib().capmi_lstm_step_supported(B, H, code))   # one launch per step
             for t in range(T):                                                                                    # :75-127
                 Gt = _p(G) + t * B * 4 * H * es
@@ -291,7 +307,10 @@ class DecoderRunner:
             # measured at cfg 2: the fused forward step wins (10.8 us vs 15.7 + 5.2), the fused backward step (16 workgroups
             # carrying the whole cell backward) loses to product + cell (18-29 us vs 7.9 + 6.0): forward only by default
             fused = self.fuse_lstm and os.environ.get('CAPMI_LSTM_FUSE', '1') == '2' and bool(lib().capmi_lstm_step_supported(B, H, code))
-            for t in reversed(range(T)):
+            if self.use_seq:      # BPTT of the layer in one launch
+                plan.add('capmi_lstm_seq_bwd', _p(G), _p(Cb), whT, 4 * H, _p(dHb), _p(dCb), _p(dG), 1 if top else 0, B, H, T,
+                         self.seq_sync.data_ptr() + 32 * l + 16, code)
+            for t in reversed(range(T if not self.use_seq else 0)):
                 blk = lambda buf, i: _p(buf) + i * B * H * es
                 Gt = _p(G) + t * B * 4 * H * es
                 dGt = _p(dG) + t * B * 4 * H * es

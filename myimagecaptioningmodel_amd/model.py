@@ -441,6 +441,12 @@ class CaptionEngine:
         self._run_captured(prog, 'graph', [prog['plan']])
         return prog['out']
 
+    def check_sync(self):
+        """Raises CapmiError if a grid barrier inside a persistent kernel gave up waiting in any step so far (reads 4 bytes
+        per launch slot back: synchronises the device)."""
+        for prog in self._train.values():
+            prog['dec'].check_sync()
+
     def decode_scores(self, B, beam):
         """Scores (sum of log-probabilities) of the best hypothesis of the last beam decode of this shape."""
         return self._eval[(B, int(beam), False)]['dec'].beam_final_score[0]
@@ -496,6 +502,7 @@ class Executor:
         out = []
         if 'loss' in names:
             loss, lr = eng.train_step(feed['image'], feed['caption'])
+            eng.check_sync()               # (the loss fetch below synchronises anyway, as train_exe.run does: train.py:139)
             res = {'loss': loss.detach().cpu().numpy().astype(np.float32),
                    self.lr_var.name: np.array([lr], dtype=np.float32)}
         elif 'caption' in names:

@@ -49,6 +49,7 @@ def train(engine, batches_per_epoch, max_epoch, checkpoint_path, log_path, log_e
         for step, data in enumerate(batches_per_epoch(epoch)):
             loss, lr = engine.train_step(data['image'], data['caption'])
             step_loss = loss.detach().cpu().numpy()
+            engine.check_sync()
             if np.isnan(step_loss).any():                       # train.py:140-141
                 raise AssertionError('Epoch:{} Step:{} Loss为Nan'.format(epoch, step + 1))
             epoch_loss += float(step_loss[0])

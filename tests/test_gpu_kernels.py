@@ -728,3 +728,112 @@ def test_adam_paddle_form_and_shadows():
     _lib.call('capmi_adam', p(P2), p(G), p(M2), p(V2), n, adam_lr_t(1e-3, 1), 0.9, 0.999, 1e-8, 0.1, 1.0, stream())
     po, _, _ = O.adam_update(pv.astype(np.float64), g.astype(np.float64), m.astype(np.float64), v.astype(np.float64), 1e-3, 1, clip=0.1)
     np.testing.assert_allclose(host(P2), po, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ persistent recurrence (capmi_lstm_seq_{fwd,bwd})
+def _seq_buffers(rng, T, B, H, E, tdt_):
+    ld = E + 2 * H
+    lw = dev(rng.standard_normal((4 * H, ld)) / np.sqrt(H), tdt_)             # lstm_w kernel layout [4H][E+H | H]
+    whT = lw[:, E + H:].t().contiguous()                                        # [H][4H]: the data-gradient form of the recurrent part
+    _KEEP.append(whT)
+    gin = dev(rng.standard_normal((T, B, 4 * H)) * 0.7, tdt_)                  # input part of the gates, every step
+    return ld, lw, whT, gin
+
+
+@pytest.mark.parametrize('dtype,B,H,T', [('f32', 64, 256, 7), ('f32', 5, 256, 3), ('bf16', 64, 512, 19), ('bf16', 33, 384, 6), ('bf16', 64, 256, 1), ('bf16', 64, 1024, 5), ('bf16', 17, 768, 4)])
+def test_persistent_lstm_sequence_against_oracle_and_per_step_launches(dtype, B, H, T):
+    """The whole recurrence of a layer in one launch per direction (grid barrier between steps) against
+    (i) oracle.ops.lstm_unit_fwd / lstm_unit_bwd (model_adaAttention_aic.py:87-88), step by step on the same inputs, and
+    (ii) the per-step launches it replaces (capmi_lstm_cell_* for the boundary step, capmi_lstm_step_* for the others):
+    forward (stored gate pre-activations, h, c) bit-identical in bf16 -- same k-split, MFMA order and rounding points --,
+    backward equal up to FMA contraction in the cell.
+    The barrier's timeout word must stay clear."""
+    _lib, tdt, code = _env()
+    L = _lib.lib()
+    assert L.capmi_lstm_seq_supported(B, H, T, code[dtype]) == 1
+    assert L.capmi_lstm_seq_supported(B, 640, T, code[dtype]) == 0 and L.capmi_lstm_seq_supported(65, H, T, code[dtype]) == 0
+    rng = np.random.RandomState(B + H + T)
+    E = 24
+    ld, lw, whT, gin = _seq_buffers(rng, T, B, H, E, tdt[dtype])
+    es = lw.element_size()
+    wh = lw.data_ptr() + (E + H) * es
+    z = lambda *s: torch.zeros(s, dtype=tdt[dtype], device=DEV)
+    sync = torch.zeros((2, 4), dtype=torch.int32, device=DEV)
+    # ---- forward: persistent
+    g_seq, h_seq, c_seq = gin.clone(), z(T + 1, B, H), z(T + 1, B, H)
+    _KEEP.extend([g_seq, h_seq, c_seq, sync])
+    _lib.call('capmi_lstm_seq_fwd', p(h_seq), wh, ld, p(g_seq), p(c_seq), B, H, T, sync.data_ptr(), code[dtype], stream())
+    # ---- forward: per-step launches (the default plan of round 1)
+    g_ref, h_ref, c_ref = gin.clone(), z(T + 1, B, H), z(T + 1, B, H)
+    _KEEP.extend([g_ref, h_ref, c_ref])
+    for t in range(T):
+        if t == 0:
+            _lib.call('capmi_lstm_cell_fwd', p(g_ref[0]), p(c_ref[0]), p(h_ref[1]), p(c_ref[1]), B, H, code[dtype], stream())
+        else:
+            _lib.call('capmi_lstm_step_fwd', p(h_ref[t]), wh, ld, p(g_ref[t]), p(c_ref[t]), p(h_ref[t + 1]), p(c_ref[t + 1]), B, H, code[dtype], stream())
+    torch.cuda.synchronize()
+    assert not sync[:, 1].any(), sync
+    assert int(sync[0, 0]) == (T - 1) * (H // 8)                    # one arrival per workgroup and barrier
+    # bf16: bit-identical; f32: the two code paths may contract a*b + c*d differently (one ulp), which the recurrence carries on
+    same = (lambda x, y: torch.equal(x, y)) if dtype == 'bf16' else (lambda x, y: torch.allclose(x, y, rtol=2e-5, atol=2e-6))
+    assert same(g_seq, g_ref) and same(h_seq, h_ref) and same(c_seq, c_ref), [float((x.float() - y.float()).abs().max()) for x, y in ((g_seq, g_ref), (h_seq, h_ref), (c_seq, c_ref))]
+    # ---- forward: oracle, step by step (f64 on the storage-rounded inputs)
+    W = rnd(host(lw), dtype).T                                        # reference layout [(E+H)+H, 4H]; x part multiplies zeros here
+    hh, cc = np.zeros((B, H)), np.zeros((B, H))
+    x0 = np.zeros((B, E + H))
+    caches = []
+    tol = dict(f32=2e-5, bf16=3e-2)[dtype]
+    for t in range(T):
+        hh, cc, cache = O.lstm_unit_fwd(x0, hh, cc, W, np.zeros(4 * H))
+        # the kernel adds the precomputed input part: fold it in by recomputing the cell from the full pre-activation
+        pre = cache[0] @ W + host(gin[t])
+        i_, f_, o_, g_ = O.sigmoid(pre[:, :H]), O.sigmoid(pre[:, H:2 * H]), O.sigmoid(pre[:, 2 * H:3 * H]), np.tanh(pre[:, 3 * H:])
+        c_prev = cache[6]
+        cc = f_ * c_prev + i_ * g_
+        hh = o_ * np.tanh(cc)
+        caches.append((cache[0], i_, f_, o_, g_, np.tanh(cc), c_prev))
+        assert np.abs(host(g_seq[t]) - pre).max() <= tol * max(1.0, np.abs(pre).max()), ('gates', t)
+        assert np.abs(host(c_seq[t + 1]) - cc).max() <= tol * max(1.0, np.abs(cc).max()), ('c', t)
+        assert np.abs(host(h_seq[t + 1]) - hh).max() <= tol, ('h', t)
+        if dtype == 'bf16':       # follow the device's rounded state, so that rounding does not accumulate into the comparison
+            hh, cc = host(h_seq[t + 1]), host(c_seq[t + 1])
+    # ---- backward
+    for top in (1, 0):
+        dh = dev(rng.standard_normal((T + 1, B, H)) * 0.1, tdt[dtype])
+        dc0 = dev(rng.standard_normal((T + 1, B, H)) * 0.1, tdt[dtype]) if top else z(T + 1, B, H)
+        dc_seq, dg_seq = dc0.clone(), z(T, B, 4 * H)
+        sync.zero_()
+        _KEEP.extend([dc_seq, dg_seq])
+        _lib.call('capmi_lstm_seq_bwd', p(g_seq), p(c_seq), p(whT), 4 * H, p(dh), p(dc_seq), p(dg_seq), top, B, H, T,
+                  sync.data_ptr() + 16, code[dtype], stream())
+        # per-step launches: capmi_lstm_cell_bwd for the last step, capmi_lstm_step_bwd (product + cell of step t-1) for the rest
+        dc_ref, dg_ref = dc0.clone(), z(T, B, 4 * H)
+        _KEEP.extend([dc_ref, dg_ref])
+        t = T - 1
+        _lib.call('capmi_lstm_cell_bwd', p(g_ref[t]), p(c_ref[t]), p(c_ref[t + 1]), p(dh[t + 1]), p(dc_ref[t + 1]) if top else None, p(dg_ref[t]),
+                  p(dc_ref[t]) if t > 0 else None, top, B, H, code[dtype], stream())
+        for t in range(T - 1, 0, -1):
+            _lib.call('capmi_lstm_step_bwd', p(dg_ref[t]), p(whT), 4 * H, p(dh[t]), p(g_ref[t - 1]), p(c_ref[t - 1]), p(c_ref[t]), p(dc_ref[t]),
+                      p(dg_ref[t - 1]), p(dc_ref[t - 1]) if t > 1 else None, top, B, H, code[dtype], stream())
+        torch.cuda.synchronize()
+        assert not sync[:, 1].any(), sync
+        assert int(sync[1, 0]) == (T - 1) * (H // 32) * ((B + 15) // 16)
+        # backward: the cell's sums of products may be contracted into FMAs differently in the two code paths (one f32 ulp,
+        # now and then one bf16 ulp after rounding) -- the tolerance test_fused_lstm_steps_equal_product_plus_cell uses
+        btol = dict(rtol=1e-5, atol=1e-6) if dtype == 'f32' else dict(rtol=8e-3, atol=1e-3)
+        assert torch.allclose(dg_seq.float(), dg_ref.float(), **btol), float((dg_seq.float() - dg_ref.float()).abs().max())
+        assert torch.allclose(dc_seq[1:].float(), dc_ref[1:].float(), **btol)
+        assert dtype == 'f32' or float((dg_seq != dg_ref).float().mean()) < 0.02      # ... and, after rounding to bf16, rare
+        # oracle BPTT with the caches of the forward pass above (f32 only: tight)
+        if dtype == 'f32':
+            dh_next = np.zeros((B, H)); dc_next = np.zeros((B, H))
+            for t in reversed(range(T)):
+                dht = host(dh[t + 1]) + dh_next
+                dct = (host(dc0[t + 1]) if top else 0.0) + dc_next
+                _dx, dh_next, dc_next, _dw, _db = O.lstm_unit_bwd(dht, dct, caches[t], W)
+                xin, i_, f_, o_, g_, tc, c_prev = caches[t]
+                do = dht * tc
+                dc_tot = dct + dht * o_ * (1 - tc * tc)
+                want = np.concatenate([dc_tot * g_ * i_ * (1 - i_), dc_tot * c_prev * f_ * (1 - f_), do * o_ * (1 - o_), dc_tot * i_ * (1 - g_ * g_)], -1)
+                got = host(dg_seq[t])
+                assert np.abs(got - want).max() <= 5e-5 * max(1.0, np.abs(want).max()), ('dG', t, np.abs(got - want).max())

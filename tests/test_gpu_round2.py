@@ -312,3 +312,42 @@ def test_plan_runner_equals_the_per_launch_host_walk(encoder, dtype, monkeypatch
                     prog['enc'].out_tensor().clone())
     assert torch.equal(fw['c'][0], fw['py'][0]) and torch.equal(fw['c'][3], fw['py'][3])
     assert all(torch.equal(a, b) for a, b in zip(fw['c'][1], fw['py'][1])) and all(torch.equal(a, b) for a, b in zip(fw['c'][2], fw['py'][2]))
+
+
+# ------------------------------------------------------------------ persistent LSTM recurrence inside the engine
+@pytest.mark.parametrize('layers', [1, 2])
+def test_engine_with_persistent_recurrence_equals_per_step_plan(layers, monkeypatch):
+    """H = 256, B = 16 bf16: the train step whose LSTM layers each run as ONE forward and ONE backward launch
+    (capmi_lstm_seq_*, grid barriers) against the same step with per-step launches (CAPMI_LSTM_SEQ=0, fused backward
+    steps CAPMI_LSTM_FUSE=2 -- the arithmetic the persistent kernels mirror): forward bit-identical, gradients equal up
+    to f32 atomic order; and against the oracle within the bf16 bounds of test_gpu_model."""
+    ocfg, ecfg = _cfgs('mobilenetv2', 'slots', 'bf16', S=64, H=256, E=64, V=120, L=7)
+    ocfg['rnn_layer'] = ecfg['rnn_layer'] = layers
+    B = 16
+    params, image, caption = _data(ocfg, B, seed=6)
+    res = {}
+    for mode, env in (('seq', {'CAPMI_LSTM_SEQ': '1'}), ('steps', {'CAPMI_LSTM_SEQ': '0', 'CAPMI_LSTM_FUSE': '2'})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = _engine(ecfg, params)
+        loss = float(eng.forward_backward(image, caption).cpu()[0])
+        dec = eng._train[B]['dec']
+        assert dec.use_seq == (mode == 'seq')
+        eng.check_sync()
+        res[mode] = dict(loss=loss, logits=dec.logits.clone(), H=[h.clone() for h in dec.Hbufs], G=[g.clone() for g in dec.Gs],
+                         dG=[g.clone() for g in dec.dGs], grads=eng.export_reference_grads(), n=len(eng._train[B]['fwd']) + len(eng._train[B]['bwd']))
+        monkeypatch.delenv('CAPMI_LSTM_FUSE', raising=False)
+    a, b = res['seq'], res['steps']
+    assert a['n'] < b['n'] - 2 * layers * (ocfg['sentence_length'] - 3)            # the per-step launches are gone
+    assert a['loss'] == b['loss'] and torch.equal(a['logits'], b['logits'])
+    assert all(torch.equal(x, y) for x, y in zip(a['H'], b['H'])) and all(torch.equal(x, y) for x, y in zip(a['G'], b['G']))
+    assert all(torch.allclose(x.float(), y.float(), rtol=8e-3, atol=1e-3) for x, y in zip(a['dG'], b['dG']))     # up to FMA contraction in the cell
+    for n, g in b['grads'].items():
+        assert np.linalg.norm(a['grads'][n] - g) <= 1e-3 * np.linalg.norm(g) + 1e-7, n
+    oracle = om.OracleModel(ocfg, {k: v.copy() for k, v in params.items()})
+    loss_o, _ = oracle.forward_train(image.astype(np.float64), caption)
+    grads_o = oracle.backward()
+    assert abs(a['loss'] - loss_o) <= 5e-2
+    for name in ('lstm_w', 'lstm_b', 'word_embedding', 'fc_7.w_0') + (('lstm_w_l1',) if layers == 2 else ()):
+        x, y = a['grads'][name].ravel(), grads_o[name].ravel()
+        assert float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30)) >= 0.97, name
