@@ -1248,13 +1248,24 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(T* hbuf, const T* __r
         aok[i] = m < B;
         aoff[i] = (unsigned)(((aok[i] ? m : 0) * H + kbeg + fg * 8) * sizeof(T));
     }
-    const int b = tid & 63, up = (tid >> 6) * 2;                // the cell: row b, units u0 + up, u0 + up + 1
+    // the cell: row b, units u0 + up, u0 + up + 1 -- four neighbouring lanes cover the workgroup's 8 units of one row (16
+    // contiguous bytes in bf16), a wave 16 rows: a gate / state access of a wave touches 16 lines, not 64 (with the row
+    // in the lane index the forward kernel took 11.6 us per step against 5.7 for the backward one)
+    const int b = tid >> 2, up = (tid & 3) * 2;
     float* tile = &red[0][0][0][0];                             // [64][33]
     const unsigned blk = (unsigned)((size_t)B * H * sizeof(T));
+    typedef T __attribute__((ext_vector_type(2))) Pair;
     for (int t = 0; t < Tn; ++t) {
         T* gt = gates + (int64_t)t * B * 4 * H;
         T* cp = cbuf + (int64_t)t * B * H;
         T* hn = hbuf + (int64_t)(t + 1) * B * H;
+        // the cell's own operands do not depend on the other workgroups: fetched before the barrier
+        Pair pg[4], pcv;
+        if (b < B) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pg[g] = *reinterpret_cast<const Pair*>(gt + (int64_t)b * 4 * H + g * H + u0 + up);
+            pcv = *reinterpret_cast<const Pair*>(cp + (int64_t)b * H + u0 + up);
+        }
         if (t > 0) {
             seq_grid_barrier(sync, (unsigned)t * gridDim.x, fences);    // every workgroup has written its part of h_{t-1} (block t)
             f32x4 acc[4][2];
@@ -1298,23 +1309,22 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(T* hbuf, const T* __r
         }
         if (b < B) {
             float hv[2];
+            Pair og[4], oc;
 #pragma unroll
             for (int uu = 0; uu < 2; ++uu) {
                 const int u = up + uu;
-                T* gr = gt + (int64_t)b * 4 * H + u0 + u;
                 float pre[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     if (t > 0) {
-                        const T stored = from_f32<T>(tile[b * 33 + 8 * g + u] + to_f32(gr[g * H]));
-                        gr[g * H] = stored;                     // the pre-activation BPTT reads back
-                        pre[g] = to_f32(stored);
+                        og[g][uu] = from_f32<T>(tile[b * 33 + 8 * g + u] + to_f32(pg[g][uu]));     // the pre-activation BPTT reads back
+                        pre[g] = to_f32(og[g][uu]);
                     } else {
-                        pre[g] = to_f32(gr[g * H]);             // h_{-1} = 0: the input part is the pre-activation
+                        pre[g] = to_f32(pg[g][uu]);             // h_{-1} = 0: the input part is the pre-activation
                     }
                 }
                 float i_, f_, o_, g_, cn;
-                const float cpv = to_f32(cp[(int64_t)b * H + u0 + u]);
+                const float cpv = to_f32(pcv[uu]);
                 if (t > 0) {        // the arithmetic of lstm_step_fwd_kernel ...
                     i_ = sigmoid_for<T>(pre[0]), f_ = sigmoid_for<T>(pre[1]), o_ = sigmoid_for<T>(pre[2]), g_ = tanh_for<T>(pre[3]);
                     cn = f_ * cpv + i_ * g_;
@@ -1324,9 +1334,14 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(T* hbuf, const T* __r
                     cn = f_ * cpv + i_ * g_;
                     hv[uu] = o_ * tanhf_(cn);
                 }
-                cp[(int64_t)B * H + (int64_t)b * H + u0 + u] = from_f32<T>(cn);     // read back by this thread only
+                oc[uu] = from_f32<T>(cn);
             }
-            store_pair_sc1(hn + (int64_t)b * H + u0 + up, hv[0], hv[1]);            // read by every workgroup in step t + 1
+            if (t > 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<Pair*>(gt + (int64_t)b * 4 * H + g * H + u0 + up) = og[g];
+            }
+            *reinterpret_cast<Pair*>(cp + (int64_t)B * H + (int64_t)b * H + u0 + up) = oc;       // read back by this thread only
+            store_pair_sc1(hn + (int64_t)b * H + u0 + up, hv[0], hv[1]);                        // read by every workgroup in step t + 1
         }
     }
 }
@@ -2160,7 +2175,8 @@ static int tn_splits(int M, int N, int K, int bno, int bko, int* per_out) {
     const long long out_elems = (long long)cdiv(N, bno) * bno * cdiv(K, bko) * bko;
     long long by_ws = (6ll << 20) / (out_elems > 0 ? out_elems : 1);
     if (by_ws < 1) by_ws = 1;
-    const int slots = 256 * (bno >= 128 ? 1 : 2);
+    static const int slots_env = getenv("CAPMI_TN_SLOTS") ? atoi(getenv("CAPMI_TN_SLOTS")) : 0;      // experiment knob
+    const int slots = slots_env > 0 ? slots_env * (bno >= 128 ? 1 : 2) : 256 * (bno >= 128 ? 1 : 2);
     int want = slots / tiles;
     int max_splits = cdiv(M, 256);
     if (max_splits > by_ws) max_splits = (int)by_ws;
@@ -2195,7 +2211,8 @@ static int launch_tn(WGradArgs& a, float* ws, long long ws_bytes, hipStream_t st
     a.Np = cdiv(a.N, BNO) * BNO;
     a.Kp = cdiv(a.K, BKO) * BKO;
     a.slab = nullptr;
-    const bool use_slab = splits > 1 && splits <= 24 && BNO >= 128;   // many splits / tiny outputs: the slab reduce would be latency-bound
+    static const int force_atomic = getenv("CAPMI_TN_ATOMIC") ? atoi(getenv("CAPMI_TN_ATOMIC")) : 0;  // experiment knob
+    const bool use_slab = splits > 1 && splits <= 24 && BNO >= 128 && !force_atomic;   // many splits / tiny outputs: the slab reduce would be latency-bound
     if (use_slab) {
         CAPMI_CHECK(ws && ws_bytes >= (long long)splits * a.Np * a.Kp * 4, "capmi_igemm_tn_wgrad: workspace too small (%lld bytes needed)",
                     (long long)splits * a.Np * a.Kp * 4);
