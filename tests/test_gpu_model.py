@@ -254,6 +254,7 @@ def test_train_step_with_fused_lstm_steps(dtype, monkeypatch):
     from myimagecaptioningmodel_amd import _lib
     from myimagecaptioningmodel_amd.decoder import DecoderRunner
     monkeypatch.setenv('CAPMI_LSTM_FUSE', '2')          # both directions (the default fuses the forward step only)
+    monkeypatch.setenv('CAPMI_LSTM_SEQ', '0')           # (the persistent whole-sequence kernels have their own tests: test_gpu_round2)
     ocfg, ecfg = _cfgs('mobilenetv2', 'slots', dtype, S=64, H=256, E=64, V=60, L=5)
     params, image, caption = _data(ocfg, 4, 21)
     eng = _engine(ecfg, params)
