@@ -30,6 +30,15 @@ enum { CAPMI_ACT_NONE = 0, CAPMI_ACT_RELU = 1, CAPMI_ACT_RELU6 = 2, CAPMI_ACT_TA
 int capmi_version(void);
 const char* capmi_last_error(void);
 
+/* Alternates.  Four entry points are NOT on the default launch plans: each is a fused form that measured slower than
+ * the launches it replaces on the ResNet-50 workload, is kept because it is the faster form at other sizes or the
+ * per-step fallback of a fused kernel, and is covered by the same parity tests as the default path:
+ *   capmi_igemm_nt_bnred     (BN-backward sums from the data-gradient epilogue; CAPMI_BNRED=1)
+ *   capmi_bn_finalize_apply  (statistics merge inside the apply kernel)
+ *   capmi_im2col_stem        (patch-matrix stem; the default is capmi_s2d_stem)
+ *   capmi_lstm_step_bwd      (one BPTT step per launch; CAPMI_LSTM_FUSE=2.  Shapes outside capmi_lstm_seq_supported
+ *                             run capmi_lstm_cell_bwd + a skinny product per step.) */
+
 /* Lane synchronisation: device-scope events ordering two HIP streams of one device (the launch plan's
  * main lane and the side lane that runs weight gradients).  No timing, no system-scope fence: a default
  * hipEventRecord writes the L2 back for the host's benefit, ~6 us of idle queue each time. */
