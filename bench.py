@@ -75,6 +75,15 @@ def pmc_traffic(label):
         hit = [v for k, v in kernels.items() if re.search(r'\b%s\b' % re.escape(label), k)]
     if len(hit) != 1:
         return None, source
+    # stale profile: the kernels changed since the pass was recorded (checkable only where the git history is present --
+    # on the GPU box the snapshot has none, there the recorded head is all that can be reported)
+    if doc.get('head') and os.path.isdir(os.path.join(ROOT, '.git')):
+        import subprocess
+        rc = subprocess.call(['git', '-C', ROOT, 'diff', '--quiet', doc['head'], 'HEAD', '--', 'myimagecaptioningmodel_amd/csrc'],
+                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        if rc != 0:
+            source['stale'] = 'csrc/ differs from the tree the pass was recorded on'
+            return None, source
     return round(hit[0]['hbm_bytes_per_launch'] / 1e6, 3), source
 
 

@@ -37,7 +37,13 @@ def main():
         f = fs / fn * 1024.0 * 2.0
         w = ws / wn * 1024.0 if wn else 0.0
         kernels[name] = dict(launches=fn, fetch_bytes_per_launch=f, write_bytes_per_launch=w, hbm_bytes_per_launch=f + w)
-    json.dump(dict(note='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches); FETCH_SIZE doubled '
+    import subprocess
+    try:
+        head = subprocess.check_output(['git', 'rev-parse', '--short=12', 'HEAD'], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        head = None          # (the GPU box has no .git: refresh_profiles.sh passes the head through CAPMI_HEAD)
+    head = os.environ.get('CAPMI_HEAD') or head
+    json.dump(dict(head=head, note='rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, eager launches); FETCH_SIZE doubled '
                         'per MI355X_MICROARCH.md (gfx950 counts 64 B per 128-B request); bytes per launch averaged over all '
                         'launches of the kernel symbol. ' + note, kernels=kernels), open(out, 'w'), indent=1)
     print('wrote', out, len(kernels), 'kernels')

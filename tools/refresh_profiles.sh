@@ -5,6 +5,7 @@
 # them (timeline / per-shape / per-queue tables), and the two PMC passes (counters on their own, kernel trace only).
 set -euo pipefail
 tag="${1:-r01}"
+export CAPMI_HEAD="${2:-}"      # head of the tree being profiled (the GPU box has no .git): tools/refresh_profiles.sh r02 $(git rev-parse --short=12 HEAD)
 out="gpurun_out/prof_$tag"
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
