@@ -102,21 +102,22 @@ class NativeComm:
         from . import _lib
         self.ok, self.why, self.comm = False, '', ctypes.c_void_p()
         L = _lib.lib()
-        ident = torch.zeros(_lib.COMM_ID_BYTES, dtype=torch.uint8)
-        flag = torch.ones(1, dtype=torch.int32, device=device)
+        # The id and the per-rank verdicts travel through the rendezvous STORE (host TCP), not through a collective of the
+        # group: torch.distributed then never has to build a communicator of its own just to carry 128 bytes.
+        store = dist.distributed_c10d._get_default_store()
+        NativeComm._serial = getattr(NativeComm, '_serial', 0) + 1
+        key = 'capmi/comm/%d/' % NativeComm._serial
         if rank == 0:
             buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
             if L.capmi_comm_unique_id(buf) != 0:
                 self.why = _lib.last_error()
-                flag.zero_()
-            ident = torch.frombuffer(bytearray(buf), dtype=torch.uint8).clone()
-        ident = ident.to(device)
-        dist.broadcast(ident, src=0, group=pg)
-        dist.broadcast(flag, src=0, group=pg)
-        if int(flag.item()) == 0:
+                store.set(key + 'id', b'')
+            else:
+                store.set(key + 'id', bytes(bytearray(buf)))
+        raw = bytes(store.get(key + 'id'))
+        if len(raw) != _lib.COMM_ID_BYTES:
             self.why = self.why or 'rank 0 could not create the RCCL unique id'
             return
-        raw = bytes(ident.cpu().numpy().tobytes())
         rc = L.capmi_comm_init(ctypes.byref(self.comm), world, rank, raw)
         if rc != 0:
             self.why = _lib.last_error()
@@ -128,9 +129,8 @@ class NativeComm:
                 self.why = _lib.last_error()
             elif not bool((t == float(world)).all()):
                 rc, self.why = 1, 'self-test: sum of ones over %d ranks gave %r' % (world, float(t[0]))
-        good = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device)
-        dist.all_reduce(good, op=dist.ReduceOp.MIN, group=pg)          # all ranks take the same path
-        self.ok = bool(int(good.item()))
+        store.set(key + 'ok/%d' % rank, b'1' if rc == 0 else b'0')          # all ranks take the same path
+        self.ok = all(bytes(store.get(key + 'ok/%d' % r)) == b'1' for r in range(world))
         if not self.ok and not self.why:
             self.why = 'another rank failed to set up its communicator'
 
@@ -164,8 +164,17 @@ class OverlappedTrainer:
         # step; any other backend (the gloo rehearsals) keeps torch.distributed and the per-segment replay below
         self.native_comm = None
         if self.active and dist.get_backend(engine.pg) == 'nccl' and os.environ.get('CAPMI_NATIVE_COMM', '1') != '0':
+            # The plan lanes' HIP streams FIRST.  ncclCommInitRank creates streams of its own; lanes created after it came out
+            # multiplexed onto the hardware queues in a way that made every kernel of the three-lane step run ~2x slower
+            # (one rank: 24-25 ms per step, with or without the all-reduce rows; 9.2 ms with the lanes created first -- the
+            # single-rank fused step takes 9.27 on the same box)
+            from ._lib import Plan
+            with torch.cuda.device(engine.device):
+                Plan._lane_streams({1, 2})
             nc = NativeComm(engine.pg, dist.get_rank(engine.pg), dist.get_world_size(engine.pg), engine.device)
-            if nc.ok:
+            if nc.ok and os.environ.get('CAPMI_NATIVE_COMM') == '2':       # timing experiment: communicator created, not used
+                self._unused_comm = nc
+            elif nc.ok:
                 self.native_comm = nc
             else:
                 import sys

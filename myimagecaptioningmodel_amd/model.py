@@ -68,6 +68,10 @@ class CaptionEngine:
                                       cfg.get('warmup_epoch', 3), cfg.get('max_epoch', 10))
         self.step_count = 0
         self._build_shadows()
+        # the side lane's HIP stream now, before anything else in the process creates streams (hardware-queue assignment
+        # follows creation order: see dp.OverlappedTrainer)
+        with torch.cuda.device(self.device):
+            Plan._lane_streams({1})
         self._train = {}      # batch size -> compiled train program
         self._eval = {}
         self.shadows_dirty = True
