@@ -403,6 +403,9 @@ def main():
         os.dup2(2, 1)
     if pg is not None:
         dist.barrier()
+        if trainer is not None and trainer.native_comm is not None:
+            torch.cuda.synchronize()
+            trainer.native_comm.close()
         dist.destroy_process_group()
 
 

@@ -71,6 +71,7 @@ class EncoderRunner:
         self.code, self.tdt = dtype_code, torch_dtype
         self.dev = store.device
         self.need_backward = need_backward
+        self.fa_max_rows = int(os.environ.get('CAPMI_BN_FA_MAXM', '0'))     # layers up to this many rows: capmi_bn_finalize_apply (0: never)
         self.fuse_bn_reduce = os.environ.get('CAPMI_BNRED', '0') == '1'     # BN backward sums from the dgrad epilogue (capmi_igemm_nt_bnred): measured slower than the streaming reduce
         enc = self.enc
         # ---- fold `add` ops into the bn_apply of the conv that produces their second operand
@@ -236,22 +237,34 @@ class EncoderRunner:
                     plan.add('capmi_bn_inference_coef', _p(st.view(op.name + '_bn_scale')), _p(st.state[op.name + '_bn_mean']),
                              _p(st.state[op.name + '_bn_variance']), BN_EPS, _p(bn['mean']), _p(bn['a']), c, lane=ln)
                 else:
-                    plan.add('capmi_bn_finalize', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')),
-                             _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS,
-                             _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, lane=ln)
+                    # small layers (stage 4 / 5 of a ResNet at batch 64): finalize inside the apply launch -- one dependent
+                    # ~5 us kernel less on the forward chain; on big layers every one of thousands of apply workgroups would
+                    # redo the merge (measured slower, capmi.h)
+                    fa_fused = M <= self.fa_max_rows
+                    if not fa_fused:
+                        plan.add('capmi_bn_finalize', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')),
+                                 _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS,
+                                 _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, lane=ln)
                 offset = _p(st.view(op.name + '_bn_offset'))
                 fa = self.fused_add.get(op.dst)
+                fused_here = (not is_test) and M <= self.fa_max_rows
+
+                def apply(res, out, act, lane):
+                    if fused_here:
+                        plan.add('capmi_bn_finalize_apply', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')), offset,
+                                 _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS,
+                                 _p(bn['mean']), _p(bn['invstd']), 1 if update_running else 0, _p(raw), res, out, act, code, lane=lane)
+                    else:
+                        plan.add('capmi_bn_apply', _p(raw), _p(bn['mean']), _p(bn['a']), offset, res, out, M, c, act, code, lane=lane)
                 if fa is None:
-                    plan.add('capmi_bn_apply', _p(raw), _p(bn['mean']), _p(bn['a']), offset, None, _p(self.act[op.dst]), M, c,
-                             ACT_CODES[op.act], code, lane=ln)
+                    apply(None, _p(self.act[op.dst]), ACT_CODES[op.act], ln)
                     if ln:
                         plan.record(('fout', op.dst), 1)
                         side_out.add(op.dst)
                 else:
                     if fa.a in side_out:
                         plan.wait(('fout', fa.a), 0)
-                    plan.add('capmi_bn_apply', _p(raw), _p(bn['mean']), _p(bn['a']), offset, _p(self.act[fa.a]), _p(self.act[fa.dst]),
-                             M, c, ACT_CODES[fa.act], code)
+                    apply(_p(self.act[fa.a]), _p(self.act[fa.dst]), ACT_CODES[fa.act], 0)
             elif isinstance(op, arch.Add):
                 n = self.act[op.dst].numel()
                 plan.add('capmi_add_act', _p(self.act[op.a]), _p(self.act[op.b]), _p(self.act[op.dst]), n, ACT_CODES[op.act], code)
