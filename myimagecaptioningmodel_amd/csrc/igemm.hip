@@ -997,6 +997,12 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma16(acc[i][j], af[i], bf[j]);
+            // The tap loop is unrolled, so without this the scheduler sinks the MFMAs of a step -- and with them the
+            // lgkmcnt wait for its fragment reads -- below the NEXT step's barrier and DMA issue: the refill of the slot
+            // those reads come from was then in flight while the reads were not yet known to have returned (WAR on LDS;
+            // a few wrong 16-row strips per launch whenever LDS traffic of a co-resident workgroup delayed the reads).
+            // Pinned here, every wave has its fragments in registers before it arrives at the barrier.
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // retire the (zero-page) tail issues before LDS reuse
@@ -1838,7 +1844,7 @@ static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, b
 // every wait replaced by vmcnt(0) (-DCAPMI_HALO_SAFE), gone with a host-side device synchronisation or an empty kernel
 // in front of the launch, or on a single stream.  Not understood; not shipped.
 static bool nt_halo3_ok(const IGemmArgs& a, const capmi_conv_geom* g, int nred) {
-    static const int mode = getenv("CAPMI_HALO3") ? atoi(getenv("CAPMI_HALO3")) : 0;
+    static const int mode = getenv("CAPMI_HALO3") ? atoi(getenv("CAPMI_HALO3")) : 1;      // 0: per-tap staging; 2 / 3: forward / data-gradient calls only
     if (mode == 0 || (mode == 2 && !a.stats) || (mode == 3 && a.stats)) return false;
     return !nred && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->up == 1 && g->pad == 1 && g->Hi == g->Ho && g->Wi == g->Wo &&
            g->os <= 1 && g->Wi <= 56 && g->Cin % 32 == 0 && a.K == 9 * g->Cin && a.N >= 32;

@@ -67,6 +67,11 @@ class DeviceFeeder:
                 t = torch.empty(max(n, 1), dtype=dtype, device=dev, pin_memory=pinned)
             return t
         idt = torch.float16 if img.dtype == np.float16 else torch.float32
+        grows = slot['d_img'] is not None and (slot['d_img'].dtype != idt or slot['d_img'].numel() < img.size or slot['d_cap'].numel() < cap.size)
+        if grows and slot['free'] is not None:
+            # the device buffers are about to be dropped: the step that still reads them (on the engine's streams, which
+            # the caching allocator knows nothing about) has to be over first
+            slot['free'].synchronize()
         slot['h_img'] = fit(slot['h_img'], img.shape, idt, self.cuda, 'cpu')
         slot['h_cap'] = fit(slot['h_cap'], cap.shape, torch.int64, self.cuda, 'cpu')
         slot['d_img'] = fit(slot['d_img'], img.shape, idt, False, self.device)

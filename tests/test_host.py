@@ -451,3 +451,19 @@ def test_checkpoint_round_trip_restores_step_moments_and_counters(tmp_path, step
     assert sorted(ckpt.load_vars_existing(e, enc_only)) == ['conv1_1_weights', 'conv9_weights']
     assert torch.equal(e.store.view('conv9_weights'), a.store.view('conv9_weights'))
     assert not torch.equal(e.store.view('lstm_w'), a.store.view('lstm_w'))
+
+
+def test_no_lds_dma_refill_over_unretired_fragment_reads():
+    """Static screen of the gfx950 assembly of the GEMM kernels (tools/lds_war_audit.py, DESIGN.md lesson 29): no LDS-DMA
+    issue may follow a barrier while ds_reads issued before that barrier are not yet retired by lgkmcnt(0) -- the
+    write-after-read on LDS that made the halo-staged 3x3 kernel irreproducible inside the two-lane step."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which('hipcc') is None:
+        pytest.skip('hipcc not on PATH')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'lds_war_audit.py'),
+                          os.path.join(root, 'myimagecaptioningmodel_amd', 'csrc', 'igemm.hip')], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().endswith('0 kernels flagged'), out.stdout[-2000:]
