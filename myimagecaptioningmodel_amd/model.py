@@ -174,10 +174,20 @@ class CaptionEngine:
         # time per step well below the device time
         fwd_enc, fwd_dec, fwd, bwd = Plan(), Plan(), Plan(), Plan()
         enc.plan_forward(fwd_enc, image, self.W)
+        # Where the encoder forward has a side lane anyway (projection shortcuts), the gradient buffer is zeroed there, under
+        # the forward pass, instead of in front of the backward pass on the critical chain; the forward plan's final join
+        # orders it before the first gradient write.  (A lane-less forward plan stays lane-less: it replays from a hipGraph.)
+        zero_in_fwd = fwd_enc.has_lanes
+        if zero_in_fwd:
+            head = Plan()
+            head.add('capmi_fill_f32', _p(self.store.grad), 0.0, self.store.size, lane=1)
+            head.extend(fwd_enc)
+            fwd_enc = head
         dec.plan_forward(fwd_dec, enc.out_tensor(), self.W)
         fwd.extend(fwd_enc)
         fwd.extend(fwd_dec)
-        bwd.add('capmi_fill_f32', _p(self.store.grad), 0.0, self.store.size)
+        if not zero_in_fwd:
+            bwd.add('capmi_fill_f32', _p(self.store.grad), 0.0, self.store.size)
         dec.plan_backward(bwd, enc.out_tensor(), enc.out_grad(), self.W, self.WT)
         marks = []
         n_dec = len(bwd)
