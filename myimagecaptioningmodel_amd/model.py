@@ -196,7 +196,7 @@ class CaptionEngine:
         prog = dict(B=B, enc=enc, dec=dec, image=image, fwd=fwd, fwd_parts=[fwd_enc, fwd_dec], bwd=bwd, graph=None, marks=marks, n_dec=n_dec)
         return prog
 
-    def _compile_eval(self, B, beam=1, is_test=False):
+    def _compile_eval(self, B, beam=1, is_test=False, scored=False):
         cfg, S = self.cfg, self.cfg['image_size']
         enc = EncoderRunner(self.store, B, S, self.code, self.tdt, False)
         enc.overlap_forward = False         # one lane: the whole decode (encoder + Ti sequential steps) replays from a hipGraph
@@ -209,14 +209,14 @@ class CaptionEngine:
         # in-training eval graph: batch statistics AND running-stat update (quirk Q3); is_test: the exported
         # inference model (infer.py) -- running statistics, nothing updated
         enc.plan_forward(plan, image, self.W, update_running=not is_test, is_test=is_test)
-        if beam <= 1:
+        if beam <= 1 and not scored:
             es = dec.Hbuf.element_size()
             for hb, cb in zip(dec.Hbufs, dec.Cbufs):                                 # zero state of every LSTM layer (:63)
                 plan.add('capmi_fill_f32', _p(hb), 0.0, B * dec.H * es // 4)
                 plan.add('capmi_fill_f32', _p(cb), 0.0, B * dec.H * es // 4)
             dec.plan_greedy(plan, enc.out_tensor(), self.W, out, Ti)
         else:
-            dec.plan_beam(plan, enc.out_tensor(), self.W, out, Ti, beam)
+            dec.plan_beam(plan, enc.out_tensor(), self.W, out, Ti, max(1, beam))
         return dict(B=B, enc=enc, dec=dec, image=image, out=out, plan=plan, graph=None, beam=beam)
 
     def _run_captured(self, prog, key, plans):
@@ -431,16 +431,18 @@ class CaptionEngine:
         self.refresh_shadows()
         return loss, lr
 
-    def decode(self, image, beam=1, is_test=False):
+    def decode(self, image, beam=1, is_test=False, scored=False):
         """Decode of the eval graph: float32 ids [B, infer_max_length] (quirk Q2).  beam = 1: the reference's greedy
         loop (:119-123); beam > 1: beam search (build-defined, see DecoderRunner.plan_beam), best hypothesis
         returned.  is_test: batch norm on the running statistics, as in the exported inference model (infer.py);
-        the default is the in-training eval graph (batch statistics, running stats updated: quirk Q3)."""
+        the default is the in-training eval graph (batch statistics, running stats updated: quirk Q3).  scored: run a
+        beam of one through the beam-search plan too, so that decode_scores() has the greedy caption's log-probability."""
         B = int(image.shape[0])
-        key = (B, int(beam), bool(is_test))
+        scored = bool(scored) and beam <= 1
+        key = (B, int(beam), bool(is_test)) + (('scored',) if scored else ())
         prog = self._eval.get(key)
         if prog is None:
-            prog = self._eval[key] = self._compile_eval(B, int(beam), bool(is_test))
+            prog = self._eval[key] = self._compile_eval(B, int(beam), bool(is_test), scored)
         if self.shadows_dirty:
             self.refresh_shadows()
         img = self._as_tensor(image, torch.float32, self.device)
@@ -449,7 +451,7 @@ class CaptionEngine:
         prog['image'].copy_(img)
         dec = prog['dec']
         dec.ids[:max(1, beam) * B].fill_(self.cfg['start_idx'])                   # :56-58
-        if beam > 1:
+        if beam > 1 or scored:
             dec.beam_score[0].fill_(-1e30)
             dec.beam_score[0][0].zero_()
         self._run_captured(prog, 'graph', [prog['plan']])
@@ -461,9 +463,11 @@ class CaptionEngine:
         for prog in self._train.values():
             prog['dec'].check_sync()
 
-    def decode_scores(self, B, beam):
-        """Scores (sum of log-probabilities) of the best hypothesis of the last beam decode of this shape."""
-        return self._eval[(B, int(beam), False)]['dec'].beam_final_score[0]
+    def decode_scores(self, B, beam, is_test=False):
+        """Scores (sum of log-probabilities) of the best hypothesis of the last beam decode of this shape (beam = 1: of the
+        last decode(..., scored=True))."""
+        key = (B, int(beam), bool(is_test)) + (('scored',) if beam <= 1 else ())
+        return self._eval[key]['dec'].beam_final_score[0]
 
 
 class ImageCaptionModel:

@@ -122,6 +122,30 @@ def test_inference_decode_is_idempotent_and_beam_one_is_greedy(full):
     assert ((a >= 0) & (a < cfg['vocab'])).all()
 
 
+def test_beam_five_at_full_size_scores_at_least_the_greedy_caption(full):
+    """BASELINE configs[4] (beam 5 at batch 64 here): ids are vocabulary indices, the decode on the running statistics is
+    idempotent, a beam of one through the beam-search plan is the greedy loop bit for bit, and the best of five hypotheses
+    scores (sum of log-probabilities over the fixed length, oracle/model.py beam_decode) at least the greedy caption on
+    every image of this seeded batch -- beam search keeps the greedy path unless five better prefixes push it out."""
+    cfg, eng, image, cap, params = full
+    greedy = eng.decode(image, is_test=True).cpu().numpy()
+    one = eng.decode(image, beam=1, is_test=True, scored=True).cpu().numpy()
+    s1 = eng.decode_scores(B, 1, is_test=True).cpu().numpy().copy()
+    five = eng.decode(image, beam=5, is_test=True).cpu().numpy().copy()
+    s5 = eng.decode_scores(B, 5, is_test=True).cpu().numpy().copy()
+    again = eng.decode(image, beam=5, is_test=True).cpu().numpy()
+    np.testing.assert_array_equal(greedy, one)
+    np.testing.assert_array_equal(five, again)
+    np.testing.assert_array_equal(s5, eng.decode_scores(B, 5, is_test=True).cpu().numpy())
+    assert five.shape == (B, cfg['infer_max_length']) and five.dtype == np.float32
+    assert ((five >= 0) & (five < cfg['vocab'])).all() and (five == np.round(five)).all()
+    assert np.isfinite(s1).all() and np.isfinite(s5).all() and (s5 <= 0).all()
+    # bf16: the 5 x 64-row decode runs other GEMM tiles (another summation order) than the 64-row one, so the same caption's
+    # logits differ by bf16 roundings (2^-8 of |logit| <= ~10 per step): scores of -20 (20 steps, V = 10 000) agree to a
+    # few 1e-2, of -125 (30 steps, V = 20 000) to ~1e-1
+    assert (s5 >= s1 - (2e-3 * np.abs(s1) + 2e-2)).all(), (s5 - s1).min()
+
+
 @pytest.mark.parametrize('workload', list(WORKLOADS))
 def test_every_encoder_layer_in_situ_against_torch_matmul(monkeypatch, workload):
     """Layer-local parity at full size, immune to the sensitivity of the random-init network (a batch permutation alone
