@@ -167,6 +167,8 @@ int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, 
  *                variance over M rows;
  *                writes saved_mean, saved_invstd, coef_a = scale*invstd, and updates the running
  *                stats with momentum (run = m*run + (1-m)*batch)
+ *                (more than 64 parts: a merge level first -- in the same launch, its last-arriving workgroup
+ *                finalizes; library-owned arrival counters, nothing for the caller to provide or zero)
  *   bn_apply   : y = act(coef_a*(x - mean) + offset (+ res))   (mean subtracted first: a*x + b
  *                with b = offset - a*mean would cancel when |mean| >> std)
  *   bn_bwd_reduce: with dz = dy * act'(y): red[0..C) += sum dz, red[C..2C) += sum dz*xhat; two

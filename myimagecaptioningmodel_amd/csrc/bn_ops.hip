@@ -8,6 +8,7 @@
 // E[x^2]-E[x]^2 cancellation anywhere.  The elementwise kernels keep ONE channel chunk per thread
 // (thread -> (cc, rr), ColLayout): coefficients live in registers, the row loop is pure 16-byte
 // traffic, and every formula subtracts the mean BEFORE scaling (as the reference's op does).
+#include <atomic>
 #include "common.h"
 
 // ------------------------------------------------------------------ statistics (standalone producer)
@@ -87,6 +88,7 @@ __device__ __forceinline__ void chan_fold(double& n, double& mean, double& m2, d
     m2 += qb + d * d * (n * nb / tot);
     n = tot;
 }
+template <bool SC1 = false>       // SC1: the parts were written by other workgroups of THIS launch (write-through): load past L1 / the local L2
 __device__ __forceinline__ void merge_parts(const float* __restrict__ ws, int part_rows, int M, int C, int c, int p0, int p1,
                                             double (*red)[64], double* mean_out, double* m2_out) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -98,15 +100,30 @@ __device__ __forceinline__ void merge_parts(const float* __restrict__ ws, int pa
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float* w = ws + ((int64_t)(p + 4 * u) * C + c) * 2;
-                mu[u] = w[0];
-                q[u] = w[1];
+                if (SC1) {
+                    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    mu[u] = __builtin_bit_cast(float, (unsigned)v);
+                    q[u] = __builtin_bit_cast(float, (unsigned)(v >> 32));
+                } else {
+                    mu[u] = w[0];
+                    q[u] = w[1];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) chan_fold(n, mean, m2, (double)min(part_rows, M - (p + 4 * u) * part_rows), (double)mu[u], (double)q[u]);
         }
         for (; p < p1; p += 4) {
             const float* w = ws + ((int64_t)p * C + c) * 2;
-            chan_fold(n, mean, m2, (double)min(part_rows, M - p * part_rows), (double)w[0], (double)w[1]);
+            float mu1, q1;
+            if (SC1) {
+                const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                mu1 = __builtin_bit_cast(float, (unsigned)v);
+                q1 = __builtin_bit_cast(float, (unsigned)(v >> 32));
+            } else {
+                mu1 = w[0];
+                q1 = w[1];
+            }
+            chan_fold(n, mean, m2, (double)min(part_rows, M - p * part_rows), (double)mu1, (double)q1);
         }
     }
     __syncthreads();                 // a second call may follow a first one's reads of red
@@ -136,11 +153,11 @@ __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int part_rows, int M, int C, const float* scale,
-                                                          float* run_mean, float* run_var, float momentum, float eps,
-                                                          float* saved_mean, float* saved_invstd, float* coef_a, int update_running) {
-    __shared__ double red[12][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+template <bool SC1>
+__device__ __forceinline__ void bn_finalize_body(const float* __restrict__ ws, int part_rows, int M, int C, int cblock, const float* scale,
+                                                 float* run_mean, float* run_var, float momentum, float eps,
+                                                 float* saved_mean, float* saved_invstd, float* coef_a, int update_running, double (*red)[64]) {
+    const int c = cblock * 64 + (threadIdx.x & 63);
     const int nparts = (M + part_rows - 1) / part_rows;
     // the per-channel scalars are fetched before the merge, not after it (one memory latency less in a kernel that is
     // nothing but latency)
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const float sc = writer ? scale[c] : 0.f;
     const float rm = writer && update_running ? run_mean[c] : 0.f, rv = writer && update_running ? run_var[c] : 0.f;
     double mean, m2;
-    merge_parts(ws, part_rows, M, C, c, 0, nparts, red, &mean, &m2);
+    merge_parts<SC1>(ws, part_rows, M, C, c, 0, nparts, red, &mean, &m2);
     if (!writer) return;
     const double var = m2 / (double)M;      // biased
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -159,6 +176,60 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         run_mean[c] = rm * momentum + (float)mean * (1.f - momentum);
         run_var[c] = rv * momentum + (float)var * (1.f - momentum);
     }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ ws, int part_rows, int M, int C, const float* scale,
+                                                          float* run_mean, float* run_var, float momentum, float eps,
+                                                          float* saved_mean, float* saved_invstd, float* coef_a, int update_running) {
+    __shared__ double red[12][64];
+    bn_finalize_body<false>(ws, part_rows, M, C, blockIdx.x, scale, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, red);
+}
+
+// Merge level and finalize in ONE launch (the merge -> finalize pair was two ~6 us dependent kernels on the forward chain
+// of 41 of the 53 layers): every workgroup merges its group of parts as bn_merge_kernel does, stores the result
+// write-through, drains the store and adds to the arrival counter of its 64-channel block; the workgroup that arrives
+// LAST (it has seen every other group's add, and each add followed that group's drained store) resets the counter and
+// finalizes the block from the merged parts, loaded past L1 / the XCD-local L2.  Same arithmetic and the same fixed fold
+// order as the two kernels; nobody waits for anybody, so the launch drains whatever the arrival order.
+__global__ __launch_bounds__(256) void bn_merge_finalize_kernel(const float* __restrict__ ws, int part_rows, int M, int C, int k, float* merged,
+                                                                unsigned* counters, const float* scale, float* run_mean, float* run_var,
+                                                                float momentum, float eps, float* saved_mean, float* saved_invstd,
+                                                                float* coef_a, int update_running) {
+    __shared__ double red[12][64];
+    __shared__ unsigned s_last;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int nparts = (M + part_rows - 1) / part_rows;
+    const int p0 = blockIdx.y * k, p1 = min(nparts, p0 + k);
+    double mean, m2;
+    merge_parts<false>(ws, part_rows, M, C, c, p0, p1, red, &mean, &m2);
+    if ((threadIdx.x >> 6) == 0 && c < C) {
+        const unsigned long long v = (unsigned long long)__builtin_bit_cast(unsigned, (float)mean) |
+                                     ((unsigned long long)__builtin_bit_cast(unsigned, (float)m2) << 32);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(merged + ((int64_t)blockIdx.y * C + c) * 2), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's write-through stores have left the chip's caches
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = old == gridDim.y - 1 ? 1u : 0u;
+        if (old == gridDim.y - 1) __hip_atomic_store(counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    bn_finalize_body<true>(merged, part_rows * k, M, C, blockIdx.x, scale, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a,
+                           update_running, red);
+}
+
+// Arrival counters of bn_merge_finalize_kernel: a pool of 128 sets of 32 (one counter per 64-channel block, C <= 2048),
+// handed out round-robin per launch and zero again when a launch ends.  Two launches share a set only when they are 128
+// launches apart in host order -- more than two training steps -- and the lanes of a step are joined at its end, so they
+// never run at the same time.
+__device__ unsigned bn_arrival_counters[128 * 32];
+static unsigned* next_arrival_counters() {
+    static std::atomic<unsigned> next{0};
+    static unsigned* base = nullptr;
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(bn_arrival_counters)) != hipSuccess) return nullptr;
+    return base + (next.fetch_add(1) % 128u) * 32u;
 }
 
 #define CAPMI_BN_MERGE_GROUPS 32     // merged groups (64 for C <= 128: few channel blocks, so more row groups); ws has room for 64 extra parts (capmi.h)
@@ -175,6 +246,16 @@ extern "C" int capmi_bn_finalize(float* ws, int part_rows, int M, int C, const f
     if (nparts > 2 * CAPMI_BN_MERGE_GROUPS) {
         const int k = cdiv(nparts, C <= 128 ? 2 * CAPMI_BN_MERGE_GROUPS : CAPMI_BN_MERGE_GROUPS);
         float* merged = ws + (int64_t)nparts * C * 2;
+        static const int fuse = getenv("CAPMI_BN_FUSE_MERGE") ? atoi(getenv("CAPMI_BN_FUSE_MERGE")) : 1;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cap);       // a captured launch would freeze its counter set into the graph
+        unsigned* counters = (fuse && C <= 2048 && cap == hipStreamCaptureStatusNone) ? next_arrival_counters() : nullptr;
+        if (counters) {
+            hipLaunchKernelGGL(bn_merge_finalize_kernel, dim3(cdiv(C, 64), cdiv(nparts, k)), dim3(256), 0, (hipStream_t)stream, ws, part_rows, M, C, k,
+                               merged, counters, scale, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running);
+            CAPMI_LAUNCH_CHECK("capmi_bn_finalize");
+            return 0;
+        }
         hipLaunchKernelGGL(bn_merge_kernel, dim3(cdiv(C, 64), cdiv(nparts, k)), dim3(256), 0, (hipStream_t)stream, ws, part_rows, M, C, k, merged);
         src = merged;
         rows = part_rows * k;

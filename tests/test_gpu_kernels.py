@@ -452,6 +452,47 @@ def test_batch_norm_statistics_no_cancellation():
     np.testing.assert_allclose(host(invstd), 1 / np.sqrt(x64.var(0) + 1e-5), rtol=1e-4)
 
 
+@pytest.mark.parametrize('M,part_rows,C', [(65 * 64, 64, 24), (12544, 128, 1024), (50176, 128, 136), (200704 + 37, 64, 64), (802816, 256, 64),
+                                           (3136 * 64, 64, 2048), (64 * 64, 64, 64)])
+def test_bn_finalize_merges_many_parts_in_one_launch(M, part_rows, C):
+    """capmi_bn_finalize over more than 64 statistic parts: the merge level and the finalize are ONE launch whose
+    last-arriving workgroup finalizes (bn_merge_finalize_kernel).  Against an f64 Chan merge of the same parts; four
+    launches back to back without a synchronisation in between (the arrival counters reset themselves, every set is
+    reused), and the running statistics must have moved exactly once per launch (a second 'last' workgroup would move
+    them twice)."""
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(M % 1000 + C)
+    nparts = (M + part_rows - 1) // part_rows
+    rows = np.minimum(part_rows, M - np.arange(nparts) * part_rows).astype(np.float64)
+    pmean = rng.standard_normal((nparts, C)) * 0.3 + rng.standard_normal(C) * 2
+    pm2 = rng.uniform(0.5, 1.5, (nparts, C)) * rows[:, None]
+    pmean32, pm232 = pmean.astype(np.float32), pm2.astype(np.float32)
+    n = rows[:, None]
+    mean = (pmean32.astype(np.float64) * n).sum(0) / M
+    m2 = (pm232.astype(np.float64) + n * (pmean32.astype(np.float64) - mean) ** 2).sum(0)
+    var = m2 / M
+    f32 = torch.float32
+    ws = torch.full((nparts + 64, C, 2), float('nan'), dtype=f32, device=DEV)
+    ws[:nparts] = dev(np.stack([pmean32, pm232], -1), f32)
+    scale = rng.uniform(0.5, 1.5, C)
+    rm0, rv0 = rng.standard_normal(C), rng.uniform(0.5, 2, C)
+    SC, RM, RV = dev(scale, f32), dev(rm0, f32), dev(rv0, f32)
+    outs = [[torch.zeros(C, dtype=f32, device=DEV) for _ in range(3)] for _ in range(4)]
+    for o in outs:
+        _lib.call('capmi_bn_finalize', p(ws), part_rows, M, C, p(SC), p(RM), p(RV), 0.9, 1e-5, p(o[0]), p(o[1]), p(o[2]), 1, stream())
+    torch.cuda.synchronize()
+    for o in outs:
+        np.testing.assert_allclose(host(o[0]), mean, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(host(o[1]), 1 / np.sqrt(var + 1e-5), rtol=2e-6)
+        np.testing.assert_allclose(host(o[2]), scale / np.sqrt(var + 1e-5), rtol=2e-6)
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])          # fixed fold order: bit-reproducible
+    want_rm, want_rv = rm0.copy(), rv0.copy()
+    for _ in range(4):
+        want_rm, want_rv = want_rm * 0.9 + mean * 0.1, want_rv * 0.9 + var * 0.1
+    np.testing.assert_allclose(host(RM), want_rm, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(RV), want_rv, rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_lstm_cell_sentinel_embedding(dtype):
     _lib, tdt, code = _env()
