@@ -15,6 +15,8 @@ timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out/trace" -
 python3 tools/trace_by_shape.py "$out/trace" 13 > "$out/${tag}_kernel_time_by_shape.txt"      # 10 timed + 3 warm-up steps: per-step columns
 python3 tools/trace_overlap.py "$out/trace" > "$out/${tag}_timeline_two_streams.txt"
 python3 tools/trace_by_queue.py "$out/trace" > "$out/${tag}_kernel_time_by_queue.txt"
+python3 tools/trace_step.py "$out/trace" > "$out/${tag}_step_timeline.txt"
+timeout -k 10 300 python3 tools/bench_layers.py 2> /dev/null > "$out/${tag}_layers_alone.txt"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-extras --no-roofline > "$out/pmc_fetch.json" 2> "$out/pmc_fetch.err"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-extras --no-roofline > "$out/pmc_write.json" 2> "$out/pmc_write.err"
 python3 tools/pmc_summary.py "$out/pmc_fetch" "$out/pmc_write" "$out/${tag}_pmc_traffic.json" "3 steps, two lanes"
