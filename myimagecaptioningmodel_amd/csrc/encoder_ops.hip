@@ -429,45 +429,59 @@ extern "C" int capmi_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int 
     CAPMI_LAUNCH_CHECK("capmi_maxpool3x3s2_fwd");
     return 0;
 }
-// one workgroup row per input row (b, hi): no 64-bit divisions per element (the flat-index form spent more
-// instructions on five of them than on the pooling itself)
+// One thread per 2 x 2 block of input pixels (rows 2i, 2i+1; columns 2j, 2j+1) and channel chunk: with k = 3, stride 2,
+// pad 1 the block's gradients come from exactly the four windows (i..i+1, j..j+1) -- pixel (even, even) is the centre of
+// window (i, j), an odd row / column sits on the edge of two windows -- so the four dy vectors and their index bytes are
+// loaded ONCE, up front and branch-free (clamped addresses, masked use), for the nine tap contributions they carry.  (One
+// thread per input pixel loaded every window again for each of its up to four pixels, behind data-dependent branches:
+// 1.4 TB/s on the 112 x 112 stem output.)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ idx, T* dx, int B, int Hi, int Wi, int cpr, int Ho, int Wo) {
     constexpr int VEC = Vec<T>::N;
+    typedef typename std::conditional<VEC == 8, uint64_t, uint32_t>::type IdxT;
+    static_assert(sizeof(IdxT) == VEC, "one index byte per vector element");
+    const int Wb = (Wi + 1) >> 1, Hb = (Hi + 1) >> 1;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= Wi * cpr) return;
-    const int wi = t / cpr, cc = t - wi * cpr;
-    const int b = blockIdx.y / Hi, hi = blockIdx.y - b * Hi;
-    float acc[VEC];
+    if (t >= Wb * cpr) return;
+    const int j = t / cpr, cc = t - j * cpr;
+    const int b = blockIdx.y / Hb, i = blockIdx.y - b * Hb;
+    Vec<T> dv[2][2];
+    IdxT iv[2][2];
+    bool ok[2][2];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int di = 0; di < 2; ++di)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int hn = hi + 1 - r;
-        if (hn < 0 || (hn & 1)) continue;
-        const int ho = hn >> 1;
-        if (ho >= Ho) continue;
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int wn = wi + 1 - q;
-            if (wn < 0 || (wn & 1)) continue;
-            const int wo = wn >> 1;
-            if (wo >= Wo) continue;
-            const int64_t o = ((((int64_t)b * Ho + ho) * Wo + wo) * cpr + cc) * VEC;
-            Vec<T> dv = vload<T>(dy + o);
-            // the VEC window indices as ONE load (they were VEC byte loads per tap)
-            typedef typename std::conditional<VEC == 8, uint64_t, uint32_t>::type IdxT;
-            static_assert(sizeof(IdxT) == VEC, "one index byte per vector element");
-            const IdxT iv = *reinterpret_cast<const IdxT*>(idx + o);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v)
-                if ((int)((iv >> (8 * v)) & 0xff) == r * 3 + q) acc[v] += dv.get(v);
+        for (int dj = 0; dj < 2; ++dj) {
+            const int ho = i + di, wo = j + dj;
+            ok[di][dj] = ho < Ho && wo < Wo;
+            const int64_t o = ((((int64_t)b * Ho + min(ho, Ho - 1)) * Wo + min(wo, Wo - 1)) * cpr + cc) * VEC;
+            dv[di][dj] = vload<T>(dy + o);
+            iv[di][dj] = *reinterpret_cast<const IdxT*>(idx + o);
         }
-    }
-    Vec<T> ov;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) ov.set(v, acc[v]);
-    vstore<T>(dx + (((int64_t)b * Hi + hi) * Wi * cpr + t) * VEC, ov);
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int hi = 2 * i + a, wi = 2 * j + c;
+            if (hi >= Hi || wi >= Wi) continue;
+            float acc[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+#pragma unroll
+            for (int di = 0; di <= a; ++di)
+#pragma unroll
+                for (int dj = 0; dj <= c; ++dj) {
+                    const int r = a ? 2 - 2 * di : 1, q = c ? 2 - 2 * dj : 1;      // hi = 2 ho - 1 + r
+                    if (!ok[di][dj]) continue;
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        if ((int)((iv[di][dj] >> (8 * v)) & 0xff) == r * 3 + q) acc[v] += dv[di][dj].get(v);
+                }
+            Vec<T> ov;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) ov.set(v, acc[v]);
+            vstore<T>(dx + ((((int64_t)b * Hi + hi) * Wi + wi) * cpr + cc) * VEC, ov);
+        }
 }
 extern "C" int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int Hi, int Wi, int C, int Ho, int Wo,
                                       int dtype, void* stream) {
@@ -475,8 +489,9 @@ extern "C" int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* 
     CAPMI_DISPATCH(dtype, "capmi_maxpool3x3s2_bwd", {
         CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_maxpool3x3s2_bwd: C not a multiple of the vector width");
         int cpr = C / Vec<T>::N;
-        CAPMI_CHECK((int64_t)B * Hi <= 65535 && (int64_t)Wi * cpr < (1ll << 30), "capmi_maxpool3x3s2_bwd: B*Hi=%lld exceeds the grid", (long long)B * Hi);
-        hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(cdiv(Wi * cpr, 256), B * Hi), dim3(256), 0, (hipStream_t)stream, (const T*)dy, idx, (T*)dx, B, Hi, Wi, cpr, Ho, Wo);
+        const int Hb = (Hi + 1) / 2, Wb = (Wi + 1) / 2;
+        CAPMI_CHECK((int64_t)B * Hb <= 65535 && (int64_t)Wi * cpr < (1ll << 30), "capmi_maxpool3x3s2_bwd: B*ceil(Hi/2)=%lld exceeds the grid", (long long)B * Hb);
+        hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(cdiv(Wb * cpr, 256), B * Hb), dim3(256), 0, (hipStream_t)stream, (const T*)dy, idx, (T*)dx, B, Hi, Wi, cpr, Ho, Wo);
     });
     CAPMI_LAUNCH_CHECK("capmi_maxpool3x3s2_bwd");
     return 0;

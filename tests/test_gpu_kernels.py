@@ -307,21 +307,21 @@ def test_depthwise(dtype, stride):
 def test_maxpool_and_stem_im2col(dtype):
     _lib, tdt, code = _env()
     rng = np.random.RandomState(3)
-    B, C, H, W = 2, 16, 9, 12
-    x = rnd(rng.standard_normal((B, C, H, W)), dtype)
-    y, idx = O.maxpool3x3s2_fwd(x)
-    Ho, Wo = y.shape[2:]
-    dy = rnd(rng.standard_normal(y.shape), dtype)
-    dx = O.maxpool3x3s2_bwd(dy, idx, x.shape)
-    X, DY = dev(_nhwc(x), tdt[dtype]), dev(_nhwc(dy), tdt[dtype])
-    Y = torch.zeros((B, Ho, Wo, C), dtype=tdt[dtype], device=DEV)
-    IDX = torch.zeros((B, Ho, Wo, C), dtype=torch.uint8, device=DEV)
-    _lib.call('capmi_maxpool3x3s2_fwd', p(X), p(Y), p(IDX), B, H, W, C, Ho, Wo, code[dtype], stream())
-    np.testing.assert_array_equal(host(Y), _nhwc(y))
-    np.testing.assert_array_equal(host(IDX), _nhwc(idx))
-    DX = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
-    _lib.call('capmi_maxpool3x3s2_bwd', p(DY), p(IDX), p(DX), B, H, W, C, Ho, Wo, code[dtype], stream())
-    check(host(DX), _nhwc(dx), dtype, name='maxpool bwd')
+    for B, C, H, W in [(2, 16, 9, 12), (3, 64, 14, 14), (1, 8, 7, 5), (2, 32, 16, 11)]:      # odd / even extents: ragged last window, ragged 2 x 2 block
+        x = rnd(rng.standard_normal((B, C, H, W)), dtype)
+        y, idx = O.maxpool3x3s2_fwd(x)
+        Ho, Wo = y.shape[2:]
+        dy = rnd(rng.standard_normal(y.shape), dtype)
+        dx = O.maxpool3x3s2_bwd(dy, idx, x.shape)
+        X, DY = dev(_nhwc(x), tdt[dtype]), dev(_nhwc(dy), tdt[dtype])
+        Y = torch.zeros((B, Ho, Wo, C), dtype=tdt[dtype], device=DEV)
+        IDX = torch.zeros((B, Ho, Wo, C), dtype=torch.uint8, device=DEV)
+        _lib.call('capmi_maxpool3x3s2_fwd', p(X), p(Y), p(IDX), B, H, W, C, Ho, Wo, code[dtype], stream())
+        np.testing.assert_array_equal(host(Y), _nhwc(y))
+        np.testing.assert_array_equal(host(IDX), _nhwc(idx))
+        DX = torch.full((B, H, W, C), float('nan'), dtype=tdt[dtype], device=DEV)             # every pixel is written
+        _lib.call('capmi_maxpool3x3s2_bwd', p(DY), p(IDX), p(DX), B, H, W, C, Ho, Wo, code[dtype], stream())
+        check(host(DX), _nhwc(dx), dtype, name='maxpool bwd %dx%d' % (H, W))
     # stem im2col + GEMM == conv on the NCHW feed
     img = rng.uniform(0, 1, (2, 3, 20, 20)).astype(np.float32)
     k, s, pad, Kpad = 7, 2, 3, 160
