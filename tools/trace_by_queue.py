@@ -4,7 +4,7 @@ import collections, csv, glob, re, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Queue_Id'], r['Kernel_Name']) for r in csv.DictReader(open(f))]
 rows.sort()
-marks = [i for i, r in enumerate(rows) if 'xent_fwd_kernel' in r[3]]
+marks = [i for i, r in enumerate(rows) if 'xent_fwd' in r[3]]
 sel = rows[marks[-4]:marks[-1]]
 
 

@@ -4,7 +4,7 @@ import collections, csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Queue_Id'], r['Kernel_Name'][:40]) for r in csv.DictReader(open(f))]
 rows.sort()
-adam = [i for i, r in enumerate(rows) if 'xent_fwd_kernel' in r[3]]      # once per train step
+adam = [i for i, r in enumerate(rows) if 'xent_fwd' in r[3]]      # once per train step
 lo, hi = adam[-4], adam[-1]            # three whole steps
 sel = rows[lo:hi]
 span = sel[-1][1] - sel[0][0]

@@ -7,7 +7,7 @@ back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Queue_Id'], r['Kernel_Name'], r.get('Grid_Size_X', r.get('Grid_Size')), r.get('Workgroup_Size_X', ''))
         for r in csv.DictReader(open(f))]
 rows.sort()
-marks = [i for i, r in enumerate(rows) if 'xent_fwd_kernel' in r[3]]
+marks = [i for i, r in enumerate(rows) if 'xent_fwd' in r[3]]
 # a step runs from the first encoder kernel (s2d_stem) before a loss kernel to the one before the next
 stems = [i for i, r in enumerate(rows) if 's2d_stem_kernel' in r[3]]
 lo = [i for i in stems if i < marks[-back]][-1]
