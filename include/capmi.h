@@ -96,6 +96,14 @@ typedef struct capmi_igemm_nt_call {
 } capmi_igemm_nt_call;
 int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count, int dtype, void* stream);
 
+/* Convolution + INFERENCE batch norm + residual + activation in ONE launch -- the exported inference model's
+ * conv2d -> batch_norm(is_test=True) -> (elementwise_add) -> relu/relu6 chain (MobileNetV2.py:99-124 under infer.py:27-31):
+ * y = act(coef_a[n] * (conv - mean[n]) + offset[n] (+ res)), capmi_bn_apply's formula applied to the f32 accumulator in
+ * the epilogue; the conv output itself never goes to memory.  mean / coef_a from capmi_bn_inference_coef. */
+int capmi_igemm_nt_bn(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                      const float* mean, const float* coef_a, const float* offset, const void* res, int ld_res,
+                      int act, int dtype, void* stream);
+
 /* Data-gradient GEMM whose OUTPUT completes the gradient of a batch-normalised tensor: capmi_igemm_nt
  * (bias, act, statistics off; output dense, ldy == N) plus, in the same epilogue, the first stage of
  * capmi_bn_bwd_reduce for the `nred` (1 or 2) layers that take this output as their dy (the layer

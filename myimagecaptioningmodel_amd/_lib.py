@@ -39,6 +39,7 @@ _g = ctypes.POINTER(ConvGeom)
 # name -> argument ctypes (the trailing `void* stream` included).  Must list every symbol of capmi.h.
 SIGNATURES = {
     'capmi_igemm_nt': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
+    'capmi_igemm_nt_bn': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     'capmi_igemm_nt_bnred': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'capmi_igemm_nt_group': [ctypes.POINTER(NtCall), _i, _i, _p],
     'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],

@@ -31,6 +31,8 @@ struct IGemmArgs {
     const void* w;
     void* y;
     const float* bias;
+    const float* bn_mean;            // inference batch norm in the epilogue (capmi_igemm_nt_bn): acc -> bn_a * (acc - bn_mean) + bias
+    const float* bn_a;
     const void* addend;
     const void* ysaved;
     float* stats;
@@ -297,7 +299,17 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
     const int wcnt = min(RW, a.M - wrow0);                     // valid rows in it (<= 0: none)
     const int col0 = n0 + wn * WN + TN * fr;                   // this lane's TN consecutive columns
     const bool rows_full = wcnt == RW;
-    if (a.bias) {
+    if (a.bn_a) {                   // the formula of bn_apply (mean subtracted before scaling), on the f32 accumulator
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const bool ok = col0 + j < a.N;
+            const float ca = ok ? a.bn_a[col0 + j] : 0.f, mu = ok ? a.bn_mean[col0 + j] : 0.f, off = ok ? a.bias[col0 + j] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = ca * (acc[i][j][r] - mu) + off;
+        }
+    } else if (a.bias) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float bias = col0 + j < a.N ? a.bias[col0 + j] : 0.f;
@@ -1783,7 +1795,7 @@ static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const
     CAPMI_CHECK(!(stats && addend), "capmi_igemm_nt: fused statistics and addend are mutually exclusive");
     CAPMI_CHECK(g->os <= 1 || (!stats && g->Hof > 0 && g->Wof > 0 && (g->Ho - 1) * g->os + g->oh0 < g->Hof && (g->Wo - 1) * g->os + g->ow0 < g->Wof),
                 "capmi_igemm_nt: bad output-scatter geometry");
-    a.x = x; a.w = w; a.y = y; a.bias = bias; a.addend = addend; a.ysaved = ysaved; a.stats = stats;
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.bn_mean = nullptr; a.bn_a = nullptr; a.addend = addend; a.ysaved = ysaved; a.stats = stats;
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldw = ldw; a.ldy = ldy; a.ld_addend = ld_addend; a.ld_saved = ld_saved;
     a.g = *g; a.act = act; a.dact = dact; a.out_f32 = out_f32;
@@ -1905,6 +1917,21 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
                               int ld_addend, const void* ysaved, int ld_saved, float* stats,
                               int act, int dact, int out_f32, int dtype, void* stream) {
     return igemm_nt_impl(x, w, y, g, N, ldw, ldy, bias, addend, ld_addend, ysaved, ld_saved, stats, act, dact, out_f32, 0, nullptr, dtype, stream);
+}
+
+/* Convolution + INFERENCE batch norm + residual + activation in one launch (the exported model of infer.py: every
+ * batch_norm is_test): y = act(coef_a * (conv - mean) + offset (+ res)), the formula of capmi_bn_apply on the f32
+ * accumulator -- the conv output never goes to memory.  mean / coef_a from capmi_bn_inference_coef. */
+extern "C" int capmi_igemm_nt_bn(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                                 const float* mean, const float* coef_a, const float* offset, const void* res, int ld_res,
+                                 int act, int dtype, void* stream) {
+    CAPMI_CHECK(mean && coef_a && offset, "capmi_igemm_nt_bn: null batch-norm vector");
+    IGemmArgs a;
+    if (nt_prepare(a, x, w, y, g, N, ldw, ldy, offset, res, ld_res, nullptr, 0, nullptr, act, 0, 0, 0, nullptr, dtype)) return 1;
+    CAPMI_CHECK(!nt_uses_skinny(g, a.M, a.K, false, dtype), "capmi_igemm_nt_bn: plain products of <= 64 rows are not convolutions");
+    a.bn_mean = mean;
+    a.bn_a = coef_a;
+    return nt_dispatch(a, g, N, nullptr, 0, dtype, (hipStream_t)stream);
 }
 
 extern "C" int capmi_igemm_nt_bnred_part_rows(const capmi_conv_geom* g, int N, int dtype) {

@@ -218,6 +218,27 @@ class EncoderRunner:
                 bn = self.bn[op.dst]
                 raw = self.raw[op.dst]
                 w = weights(op.name + '_weights')
+                if is_test and op.groups == 1:
+                    # exported inference model: conv -> batch_norm(is_test) -> (add) -> activation as ONE launch -- the
+                    # normalisation, the residual and the activation sit in the GEMM epilogue (capmi_igemm_nt_bn)
+                    plan.add('capmi_bn_inference_coef', _p(st.view(op.name + '_bn_scale')), _p(st.state[op.name + '_bn_mean']),
+                             _p(st.state[op.name + '_bn_variance']), BN_EPS, _p(bn['mean']), _p(bn['a']), c, lane=ln)
+                    fa = self.fused_add.get(op.dst)
+                    if fa is not None and fa.a in side_out:
+                        plan.wait(('fout', fa.a), 0)
+                    res, out, act = (_p(self.act[fa.a]), self.act[fa.dst], fa.act) if fa is not None else (None, self.act[op.dst], op.act)
+                    if op.src == 0:
+                        plan.add('capmi_s2d_stem', _p(image), _p(self.s2d), B, op.cin, self.S, self.S, op.pad, self.stem_hb, self.stem_wb,
+                                 self.stem_cs, code)
+                        xin, g, K = self.s2d, self._stem_geom(op), self.kpad_of(op)
+                    else:
+                        xin, g, K = self.act[op.src], self._conv_geom(op), op.k * op.k * op.cin
+                    plan.add('capmi_igemm_nt_bn', _p(xin), _p(w), _p(out), g, c, K, c, _p(bn['mean']), _p(bn['a']),
+                             _p(st.view(op.name + '_bn_offset')), res, c, ACT_CODES[act], code, lane=(0 if fa is not None else ln))
+                    if ln and fa is None:
+                        plan.record(('fout', op.dst), 1)
+                        side_out.add(op.dst)
+                    continue
                 if op.src == 0:        # stem: space-to-depth of the NCHW feed, then an ordinary stride-1 implicit GEMM
                     plan.add('capmi_s2d_stem', _p(image), _p(self.s2d), B, op.cin, self.S, self.S, op.pad, self.stem_hb, self.stem_wb,
                              self.stem_cs, code)

@@ -494,6 +494,48 @@ def test_bn_finalize_merges_many_parts_in_one_launch(M, part_rows, C):
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('B,C,H,W,Co,k,s,pad,act,res', [(2, 16, 9, 9, 24, 3, 1, 1, 'relu', False), (3, 32, 8, 8, 16, 1, 1, 0, None, True),
+                                                         (2, 64, 14, 14, 64, 3, 1, 1, 'relu', True), (2, 16, 8, 8, 32, 1, 2, 0, 'relu6', False),
+                                                         (8, 256, 14, 14, 1024, 1, 1, 0, 'relu', True)])
+def test_conv_with_inference_batch_norm_in_the_epilogue(dtype, B, C, H, W, Co, k, s, pad, act, res):
+    """capmi_igemm_nt_bn: conv -> batch_norm(is_test) -> (+ residual) -> activation in one launch, against the oracle's
+    conv + running-statistics normalisation, and against capmi_igemm_nt + capmi_bn_apply (f32: the same formula on the
+    same accumulator; bf16: one rounding fewer)."""
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(B * C + Co + k)
+    x = rnd(rng.standard_normal((B, C, H, W)), dtype)
+    w = rnd(rng.standard_normal((Co, C, k, k)) / np.sqrt(C * k * k), dtype)
+    y = O.conv2d_fwd(x, w, s, pad)
+    Ho, Wo = y.shape[2], y.shape[3]
+    scale, offset = rng.uniform(0.5, 1.5, Co), rng.standard_normal(Co) * 0.2
+    rm, rv = rng.standard_normal(Co) * 0.3, rng.uniform(0.5, 2, Co)
+    r = rnd(rng.standard_normal(y.shape), dtype) if res else None
+    a = scale / np.sqrt(rv + 1e-5)
+    pre = a[None, :, None, None] * (y - rm[None, :, None, None]) + offset[None, :, None, None] + (r if res else 0)
+    want = O.relu6(pre) if act == 'relu6' else O.relu(pre) if act == 'relu' else pre
+    f32 = torch.float32
+    X = dev(_nhwc(x), tdt[dtype])
+    Wk = dev(w.transpose(0, 2, 3, 1), tdt[dtype])
+    SC, OF, RM, RV = dev(scale, f32), dev(offset, f32), dev(rm, f32), dev(rv, f32)
+    mean, ca = torch.zeros(Co, dtype=f32, device=DEV), torch.zeros(Co, dtype=f32, device=DEV)
+    _lib.call('capmi_bn_inference_coef', p(SC), p(RM), p(RV), 1e-5, p(mean), p(ca), Co, stream())
+    R = dev(_nhwc(r), tdt[dtype]) if res else None
+    Y = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+    g = _lib.ConvGeom(B, H, W, C, Ho, Wo, k, k, s, 1, pad, C)
+    ac = _lib.ACT_CODES[act]
+    _lib.call('capmi_igemm_nt_bn', p(X), p(Wk), p(Y), g, Co, k * k * C, Co, p(mean), p(ca), p(OF), p(R), Co, ac, code[dtype], stream())
+    check(host(Y), _nhwc(want), dtype, name='conv + inference bn')
+    RAW = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+    Y2 = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+    _lib.call('capmi_igemm_nt', p(X), p(Wk), p(RAW), g, Co, k * k * C, Co, None, None, 0, None, 0, None, 0, 0, 0, code[dtype], stream())
+    _lib.call('capmi_bn_apply', p(RAW), p(mean), p(ca), p(OF), p(R), p(Y2), B * Ho * Wo, Co, ac, code[dtype], stream())
+    torch.cuda.synchronize()
+    d = (Y.float() - Y2.float()).abs().max()
+    tol = 1e-5 if dtype == 'f32' else 2 ** -6
+    assert float(d) <= tol * max(1.0, float(Y2.float().abs().max())), float(d)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_lstm_cell_sentinel_embedding(dtype):
     _lib, tdt, code = _env()
     rng = np.random.RandomState(11)
