@@ -196,6 +196,10 @@ int capmi_bn_apply(const void* x, const float* saved_mean, const float* coef_a, 
  * coef_a = scale / sqrt(running variance + eps); follow with capmi_bn_apply. */
 int capmi_bn_inference_coef(const float* scale, const float* run_mean, const float* run_var, float eps, float* mean,
                             float* coef_a, int C, void* stream);
+/* The same for every batch-norm layer of a model in one launch.  jobs: device array of
+ *   struct { const float* scale, *run_mean, *run_var; float* mean, *coef_a; int64 C; }   (48 bytes per layer);
+ * max_c = the largest C among them. */
+int capmi_bn_inference_coef_batched(const void* jobs, int njobs, int max_c, float eps, void* stream);
 /* capmi_bn_finalize + capmi_bn_apply in ONE launch (plus the merge launch for > 64 parts): every apply workgroup
  * merges the statistic groups of its own channels (f64, Chan) before normalising its rows; saved mean / invstd and
  * the running statistics are written by the first workgroup row.  Same results as the two calls.  Measured

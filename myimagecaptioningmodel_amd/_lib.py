@@ -56,6 +56,7 @@ SIGNATURES = {
     'capmi_bn_finalize': [_p, _i, _i, _i, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p],
     'capmi_bn_apply': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_inference_coef': [_p, _p, _p, _f, _p, _p, _i, _p],
+    'capmi_bn_inference_coef_batched': [_p, _i, _i, _f, _p],
     'capmi_bn_finalize_apply': [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _i, _p, _p, _p, _i, _i, _p],
     'capmi_bn_bwd_reduce': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_reduce_final': [_p, _i, _i, _p, _p],

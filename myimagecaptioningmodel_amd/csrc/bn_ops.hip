@@ -398,6 +398,23 @@ __global__ __launch_bounds__(256) void bn_inference_coef_kernel(const float* __r
     mean[c] = run_mean[c];
     coef_a[c] = scale[c] / sqrtf(run_var[c] + eps);
 }
+// every batch-norm layer of a model in ONE launch (the decode graph had one ~5 us launch per layer in front of its conv)
+struct BnCoefJob { const float* scale; const float* run_mean; const float* run_var; float* mean; float* coef_a; long long C; };
+static_assert(sizeof(BnCoefJob) == 48, "capmi.h documents 48-byte jobs");
+__global__ __launch_bounds__(256) void bn_inference_coef_batched_kernel(const BnCoefJob* __restrict__ jobs, float eps) {
+    const BnCoefJob j = jobs[blockIdx.y];
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < (int)j.C; c += gridDim.x * 256) {
+        j.mean[c] = j.run_mean[c];
+        j.coef_a[c] = j.scale[c] / sqrtf(j.run_var[c] + eps);
+    }
+}
+extern "C" int capmi_bn_inference_coef_batched(const void* jobs, int njobs, int max_c, float eps, void* stream) {
+    CAPMI_CHECK(jobs && njobs >= 1 && njobs <= 65535 && max_c >= 1, "capmi_bn_inference_coef_batched: bad arguments");
+    hipLaunchKernelGGL(bn_inference_coef_batched_kernel, dim3(cdiv(max_c, 256) < 8 ? cdiv(max_c, 256) : 8, njobs), dim3(256), 0, (hipStream_t)stream,
+                       (const BnCoefJob*)jobs, eps);
+    CAPMI_LAUNCH_CHECK("capmi_bn_inference_coef_batched");
+    return 0;
+}
 extern "C" int capmi_bn_inference_coef(const float* scale, const float* run_mean, const float* run_var, float eps, float* mean,
                                        float* coef_a, int C, void* stream) {
     CAPMI_CHECK(scale && run_mean && run_var && mean && coef_a, "capmi_bn_inference_coef: null pointer");

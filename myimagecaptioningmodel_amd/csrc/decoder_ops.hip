@@ -738,9 +738,18 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
     const float* row = logits + (int64_t)m * ld;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 256) {
-        float f = row[i];
-        if (f > best || (f == best && i < bi)) { best = f; bi = i; }
+    if (ld % 4 == 0 && ((uintptr_t)logits & 15) == 0) {         // 16-byte loads, four columns per lane (ascending index inside a lane)
+        for (int i = tid * 4; i < V; i += 1024) {
+            const f32x4 f = *reinterpret_cast<const f32x4*>(row + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i + e < V && f[e] > best) { best = f[e]; bi = i + e; }
+        }
+    } else {
+        for (int i = tid; i < V; i += 256) {
+            float f = row[i];
+            if (f > best || (f == best && i < bi)) { best = f; bi = i; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

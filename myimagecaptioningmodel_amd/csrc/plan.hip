@@ -70,6 +70,7 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_bn_finalize),
     CAPMI_ENTRY(capmi_bn_apply),
     CAPMI_ENTRY(capmi_bn_inference_coef),
+    CAPMI_ENTRY(capmi_bn_inference_coef_batched),
     CAPMI_ENTRY(capmi_bn_finalize_apply),
     CAPMI_ENTRY(capmi_bn_bwd_reduce),
     CAPMI_ENTRY(capmi_bn_bwd_reduce_final),

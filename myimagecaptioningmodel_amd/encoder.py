@@ -205,6 +205,17 @@ class EncoderRunner:
                 if isinstance(p, arch.ConvBN) and p.act is None and p.dst not in self.fused_add and self._consumers.get(p.dst, 0) == 1 \
                         and p.src != 0 and p.groups == 1:
                     side_ops.add(id(p))
+        if is_test:
+            # inference coefficients (mean = running mean, a = scale / sqrt(running variance + eps)) of EVERY layer in one launch
+            import numpy as np
+            convs = [o for o in self.enc.ops if isinstance(o, arch.ConvBN) and id(o) not in self.skipped]
+            table = np.zeros((len(convs), 6), dtype=np.int64)
+            for i, o in enumerate(convs):
+                c = self.shape[o.dst][2]
+                table[i] = (_p(st.view(o.name + '_bn_scale')), _p(st.state[o.name + '_bn_mean']), _p(st.state[o.name + '_bn_variance']),
+                            _p(self.bn[o.dst]['mean']), _p(self.bn[o.dst]['a']), c)
+            self.coef_jobs = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(self.dev)
+            plan.add('capmi_bn_inference_coef_batched', _p(self.coef_jobs), len(convs), int(table[:, 5].max()), BN_EPS)
         for op in self.enc.ops:
             if id(op) in self.skipped:
                 continue
@@ -221,8 +232,6 @@ class EncoderRunner:
                 if is_test and op.groups == 1:
                     # exported inference model: conv -> batch_norm(is_test) -> (add) -> activation as ONE launch -- the
                     # normalisation, the residual and the activation sit in the GEMM epilogue (capmi_igemm_nt_bn)
-                    plan.add('capmi_bn_inference_coef', _p(st.view(op.name + '_bn_scale')), _p(st.state[op.name + '_bn_mean']),
-                             _p(st.state[op.name + '_bn_variance']), BN_EPS, _p(bn['mean']), _p(bn['a']), c, lane=ln)
                     fa = self.fused_add.get(op.dst)
                     if fa is not None and fa.a in side_out:
                         plan.wait(('fout', fa.a), 0)
@@ -254,10 +263,7 @@ class EncoderRunner:
                     K = op.k * op.k * op.cin
                     plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
                              None if is_test else _p(bn['stats']), 0, 0, 0, code, lane=ln)
-                if is_test:
-                    plan.add('capmi_bn_inference_coef', _p(st.view(op.name + '_bn_scale')), _p(st.state[op.name + '_bn_mean']),
-                             _p(st.state[op.name + '_bn_variance']), BN_EPS, _p(bn['mean']), _p(bn['a']), c, lane=ln)
-                else:
+                if not is_test:
                     # small layers (stage 4 / 5 of a ResNet at batch 64): finalize inside the apply launch -- one dependent
                     # ~5 us kernel less on the forward chain; on big layers every one of thousands of apply workgroups would
                     # redo the merge (measured slower, capmi.h)
