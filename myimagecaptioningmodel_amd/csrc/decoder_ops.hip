@@ -896,51 +896,56 @@ __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* __restr
         }
     }
 }
-// Step 2 (one thread per image): the `beam` best of the beam x beam candidates by score[k] + logit - lse[k];
-// writes the new scores, (parent, token) of step t, the next input ids and the state-gather rows.  Every candidate is
-// loaded up front (the kernel is one wave per 64 images: all latency), the rounds then run on registers.
-__global__ __launch_bounds__(64) void beam_select_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
-                                                         const float* __restrict__ lse, const float* __restrict__ score_in, int B, int beam,
-                                                         float* score_out, int* parents, int* tokens, int64_t* next_ids, int* gather_rows) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
-    float tot[8][8];
-    int tok[8][8];
+// Step 2: the `beam` best of the beam x beam candidates by score[k] + logit - lse[k]; writes the new scores, (parent,
+// token) of step t, the next input ids and the state-gather rows.  Eight lanes per image, lane k owns source hypothesis k:
+// its candidates arrive sorted (value desc, token asc), so the selection is a `beam`-round merge of up to 8 sorted lists --
+// every lane offers the head of its list, three xor-shuffles pick the winner (total desc, then the lower k: the order
+// the one-thread-per-image form visited them in), the winner advances.  (That form took 21-28 us per step: one wave,
+// 5 x 64 dependent compares per lane.)
+__global__ __launch_bounds__(256) void beam_select_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                          const float* __restrict__ lse, const float* __restrict__ score_in, int B, int beam,
+                                                          float* score_out, int* parents, int* tokens, int64_t* next_ids, int* gather_rows) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = t >> 3, k = t & 7;
+    const bool live = b < B && k < beam;
+    const int row = live ? k * B + b : 0;
+    float tot[8];
+    int tok[8];
+    const float base = live ? score_in[row] - lse[row] : 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int row = (k < beam ? k : 0) * B + b;
-        const float base = score_in[row] - lse[row];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const bool ok = k < beam && r < beam;
-            const int64_t o = (int64_t)row * beam + (r < beam ? r : 0);
-            tot[k][r] = ok ? base + cand_val[o] : -INFINITY;
-            tok[k][r] = ok ? cand_idx[o] : 0x7fffffff;
-        }
+    for (int r = 0; r < 8; ++r) {
+        const bool ok = live && r < beam;
+        const int64_t o = (int64_t)row * beam + (r < beam ? r : 0);
+        tot[r] = ok ? base + cand_val[o] : -INFINITY;
+        tok[r] = ok ? cand_idx[o] : 0x7fffffff;
     }
-    unsigned long long used = 0;           // candidate (k, r) -> bit k*8 + r
+    int head = 0;                                       // next unused candidate of this lane's list
     for (int j = 0; j < beam; ++j) {
-        float best = -INFINITY;
-        int bk = 0, br = 0, bt = 0x7fffffff;
-        bool any = false;
+        float hv = -INFINITY;
+        int ht = 0x7fffffff;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
+        for (int r = 0; r < 8; ++r)
+            if (r == head) { hv = tot[r]; ht = tok[r]; }
+        int key = (live && head < beam) ? k : 8 + k;    // exhausted / idle lanes lose against any live one
+        float bv = hv;
+        int bk = key, bt = ht;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (k >= beam || r >= beam || (used >> (k * 8 + r) & 1ull)) continue;
-                // candidates are visited in (k asc, value desc / token asc) order: strict > keeps the first of a tie,
-                // except that equal totals inside one row must still prefer the lower token id
-                if (!any || tot[k][r] > best || (tot[k][r] == best && k == bk && tok[k][r] < bt)) {
-                    best = tot[k][r]; bk = k; br = r; bt = tok[k][r]; any = true;
-                }
-            }
-        used |= 1ull << (bk * 8 + br);
-        const int o = j * B + b;
-        score_out[o] = best;
-        parents[o] = bk;
-        tokens[o] = bt;
-        next_ids[o] = bt;
-        gather_rows[o] = bk * B + b;
+        for (int o = 1; o < 8; o <<= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int ok2 = __shfl_xor(bk, o, 64), ot = __shfl_xor(bt, o, 64);
+            const bool mine_dead = bk >= 8, other_dead = ok2 >= 8;
+            const bool take = mine_dead != other_dead ? mine_dead : (ov > bv || (ov == bv && ok2 < bk));
+            if (take) { bv = ov; bk = ok2; bt = ot; }
+        }
+        if (bk == k && live) ++head;                    // this lane's head was taken
+        if (k == 0 && b < B) {
+            const int o = j * B + b;
+            score_out[o] = bv;
+            parents[o] = bk & 7;
+            tokens[o] = bt;
+            next_ids[o] = bt;
+            gather_rows[o] = (bk & 7) * B + b;
+        }
     }
 }
 extern "C" int capmi_beam_step(const float* logits, int V, int ld, int B, int beam, const float* score_in, float* score_out,
@@ -953,7 +958,7 @@ extern "C" int capmi_beam_step(const float* logits, int V, int ld, int B, int be
     if (vec && V <= 1024 * 10) hipLaunchKernelGGL(beam_topk_reg_kernel<10>, dim3(beam * B), dim3(256), 0, (hipStream_t)stream, logits, V, ld, beam, cand_val, cand_idx, lse);
     else if (vec && V <= 1024 * 20) hipLaunchKernelGGL(beam_topk_reg_kernel<20>, dim3(beam * B), dim3(256), 0, (hipStream_t)stream, logits, V, ld, beam, cand_val, cand_idx, lse);
     else hipLaunchKernelGGL(beam_topk_kernel, dim3(beam * B), dim3(256), 0, (hipStream_t)stream, logits, V, ld, beam, cand_val, cand_idx, lse);
-    hipLaunchKernelGGL(beam_select_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, cand_val, cand_idx, lse, score_in, B, beam,
+    hipLaunchKernelGGL(beam_select_kernel, dim3(cdiv(B, 32)), dim3(256), 0, (hipStream_t)stream, cand_val, cand_idx, lse, score_in, B, beam,
                        score_out, parents, tokens, next_ids, gather_rows);
     CAPMI_LAUNCH_CHECK("capmi_beam_step");
     return 0;
