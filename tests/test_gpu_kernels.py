@@ -705,7 +705,7 @@ def test_beam_step_gather_backtrack(B, beam, V):
     ties go to the lower beam index, then the lower token id (stable descending sort of the flat [beam*V] totals)."""
     _lib, tdt, code = _env()
     rng = np.random.RandomState(B + beam + V)
-    ld = (V + 7) // 8 * 8
+    ld = V if V == 37 else (V + 7) // 8 * 8          # 37: an unpadded, odd row pitch (the scalar kernels); else the 16-byte-load kernels
     Ti = 3
     logits = np.round(rng.standard_normal((Ti, beam * B, ld)) * 2) / 2          # coarse values: many exact ties
     score = np.zeros((beam, B), np.float32)
@@ -756,7 +756,7 @@ def test_beam_step_gather_backtrack(B, beam, V):
 def test_softmax_xent_argmax(V):
     _lib, tdt, code = _env()
     rng = np.random.RandomState(V)
-    M, ld = 37, (V + 7) // 8 * 8
+    M, ld = 37, (V if V == 50 else (V + 7) // 8 * 8)      # 50: row pitch not a multiple of 4 (the scalar kernels)
     logits = np.zeros((M, ld), np.float32)
     logits[:, :V] = rng.standard_normal((M, V)).astype(np.float32) * 3
     tgt = rng.randint(1, V, size=M).astype(np.int64)
