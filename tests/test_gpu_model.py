@@ -3,8 +3,12 @@ NumPy oracle on the same seeded inputs and parameters -- loss, logits, every par
 gradient, Paddle-form Adam updates, BN running statistics and greedy token ids.
 
 Tolerances (stated per BASELINE.json's north_star: loss within 1e-3, argmax ids bit-exact):
-  f32 engine vs f64 oracle: |loss| <= 1e-4, gradients <= 2e-3 of each tensor's max |g|,
-  greedy ids bit-exact; bf16 engine: |loss| <= 5e-2, gradient direction cos >= 0.97.
+  f32 engine vs f64 oracle: |loss| <= 1e-4; all gradients together <= max(2e-3, 10 x the noise floor) relative L2, where
+  the noise floor is the SAME oracle run in f32 against itself in f64 (measured 2e-3 .. 3e-2: batch norm at random
+  initialisation amplifies f32 rounding); each tensor <= max(5 %, 20 x its own f32 noise) -- the test
+  prints the worst tensor and the worst error-to-noise ratio (observed: 0.6 .. 14, i.e. the kernels sit AT the f32 noise
+  of the model, which is what bounds a per-tensor claim, not the kernels); greedy ids bit-exact;
+  bf16 engine: |loss| <= 5e-2, gradient direction cos >= 0.97.
 """
 import numpy as np
 import pytest
@@ -85,7 +89,7 @@ def test_f32_train_step_matches_oracle(encoder, attention, S):
         tot = np.sqrt(sum(np.sum(g ** 2) for g in grads_o.values()))
         print('step %d total relative-L2 gradient error %.2e (f32 NumPy noise floor %.2e)' % (step, tot_err / tot, tot_noise / tot))
         assert tot_err / tot <= max(2e-3, 10 * tot_noise / tot), (step, tot_err / tot, tot_noise / tot)
-        worst = (0.0, None)
+        worst, ratio = (0.0, None), (0.0, None)
         for name, go in grads_o.items():
             ge = grads_e[name]
             floor = 1e-6 * gscale * np.sqrt(go.size)
@@ -95,7 +99,9 @@ def test_f32_train_step_matches_oracle(encoder, attention, S):
             assert err <= max(5e-2 * nrm, 20 * noise, floor), (step, name, err / (nrm + 1e-30), noise / (nrm + 1e-30))
             if nrm > floor:
                 worst = max(worst, (err / nrm, name))
-        print('step %d worst relative-L2 gradient error %.2e (%s)' % (step, worst[0], worst[1]))
+                ratio = max(ratio, (err / max(noise, 2e-3 * nrm, floor), name))
+        print('step %d worst relative-L2 gradient error %.2e (%s); worst error / max(f32 noise of that tensor, 2e-3) = %.2f (%s)' % (
+            step, worst[0], worst[1], ratio[0], ratio[1]))
         if attention == 'singleton':      # quirk Q1: exactly zero gradient, parameters never move
             for n in ('fc_3', 'fc_8', 'fc_9', 'fc_10'):
                 assert np.all(grads_e[n + '.w_0'] == 0) and np.all(grads_e[n + '.b_0'] == 0)
