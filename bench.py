@@ -282,6 +282,8 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: the BASELINE config: 64 train, 128 decode)')
     ap.add_argument('--decode', action='store_true', help='BASELINE configs[4]: beam-search decode captions/sec + p50 latency (extra mode)')
     ap.add_argument('--beam', type=int, default=5)
+    ap.add_argument('--config', type=int, default=1, choices=[1, 3], help='1 (default): the bench workload, BASELINE configs[1]; 3: BASELINE configs[3] '
+                    '(ResNet-101 + 2-layer 1024-d LSTM, 384x384, L = 30, V = 20 000) as its own JSON line -- an extra mode like --decode')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra lines (singleton attention, f32, loss gap)')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -308,7 +310,10 @@ def main():
     dev = 'cuda:%d' % local
     torch.cuda.set_device(local)
     B = args.batch or PER_GPU_BATCH
-    cfg = default_cfg(batch_size=B * world, sample_count=0, **WORKLOAD)
+    workload = WORKLOAD_CFG3 if args.config == 3 else WORKLOAD
+    if args.config == 3:            # extra mode: its own metric line, no roofline / extras / CPU baseline (those describe the bench workload)
+        args.no_roofline = args.no_extras = args.no_cpu_baseline = True
+    cfg = default_cfg(batch_size=B * world, sample_count=0, **workload)
     eng = CaptionEngine(cfg, device=dev, use_graph=not args.no_graph, process_group=pg)
     trainer = dp.OverlappedTrainer(eng) if pg is not None else None      # (CAPMI_FORCE_DP=1: the N > 1 path on one rank)
     image, cap = synthetic_batch(B, cfg, 1234 + rank)
@@ -346,11 +351,15 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         out = {
-            'metric': 'train images/sec (224x224, seq_len=20, vocab~10k)', 'value': round(B * world * args.steps / dt, 2),
+            'metric': ('train images/sec (224x224, seq_len=20, vocab~10k)' if args.config == 1 else
+                       'train images/sec (384x384, seq_len=30, vocab 20k, ResNet-101 + 2-layer 1024-d LSTM)'),
+            'value': round(B * world * args.steps / dt, 2),
             'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: ResNet-50 (build-defined) + 512-d adaptive-attention LSTM decoder, '
-                                   'vocab 10000, 224x224, seq_len 20, E=H=512, attention=slots, random-init weights',
+            'config': {'workload': ('BASELINE configs[1]: ResNet-50 (build-defined) + 512-d adaptive-attention LSTM decoder, '
+                                    'vocab 10000, 224x224, seq_len 20, E=H=512, attention=slots, random-init weights' if args.config == 1 else
+                                    'BASELINE configs[3]: ResNet-101 (build-defined) + 2-layer 1024-d adaptive-attention LSTM decoder, '
+                                    'vocab 20000, 384x384, seq_len 30, E=H=1024, attention=slots, random-init weights'),
                        'per_gpu_batch': B, 'global_batch': B * world, 'parallelism': 'dp%d' % world,
                        # what ran in the timed region: laned plans are enqueued eagerly through capmi_plan_run (one foreign
                        # call per plan) on HIP streams; no hipGraph replays there (hipGraph serialises parallel branches)
