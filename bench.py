@@ -24,6 +24,7 @@ if ROOT not in sys.path:
 WORKLOAD = dict(encoder='resnet50', image_size=224, hidden=512, embed=512, vocab=10000, sentence_length=20,
                 infer_max_length=20, attention='slots', dtype='bf16', learning_rate=5e-5, encoder_trainable=True)
 PER_GPU_BATCH = 64
+FLOPS_PER_IMAGE = {1: 26.18e9, 3: 149.9e9}      # 6 x forward GEMM-class MACs (cfg 2/3: 4.363 GMAC; cfg 4: 24.98 GMAC)
 # BASELINE configs[3] (a parity / stress case, not the bench line): ResNet-101 + 2-layer 1024-d LSTM decoder, 384x384,
 # seq_len 30, vocab 20k, 64 images per GPU (512 over 8).  E = H = 1024 and Ti = L are this build's reading of the
 # unspecified sizes (SURVEY.md section 8, table of configs)
@@ -169,7 +170,7 @@ def _cpu_train_steps(ocfg, B, warm, steps, seed, deadline):
     return (sum(times) / len(times), len(times)) if times else (dt, 0)
 
 
-def cpu_baseline(cfg, budget_s=25.0):
+def cpu_baseline(cfg, budget_s=25.0, probe_batch=8, max_batch=64, label='bench workload (ResNet-50, 224x224, V 10000, L 20)'):
     """'build's CPU restatement of the reference graph, not PaddlePaddle' (Paddle 1.8 is not
     installable here) = the torch-CPU build of the identical graph (tests/torch_ref.py), whole train steps (fwd + bwd +
     Paddle-form Adam) in fp32 on the box's host cores, 2 warm-up + >= 5 timed steps: BASELINE cfg 1 (repo-default
@@ -185,20 +186,20 @@ def cpu_baseline(cfg, budget_s=25.0):
                            infer_max_length=10, attention='singleton')
     s1, n1 = _cpu_train_steps(ocfg1, 4, 2, 5, 1234, t_start + 0.3 * budget_s)
     ocfg2 = om.default_cfg(**{k: cfg[k] for k in ('encoder', 'image_size', 'hidden', 'embed', 'vocab', 'sentence_length',
-                                                  'infer_max_length', 'attention')})
-    # probe at batch 8, then the largest power-of-two batch <= 64 whose 2 + 5 steps fit what is left of the budget
-    progress('cpu baseline: cfg 1 %.3f s/step; probing the bench workload at batch 8' % s1)
-    probe, _ = _cpu_train_steps(ocfg2, 8, 1, 1, 1234, time.perf_counter() + 60.0)
+                                                  'infer_max_length', 'attention', 'rnn_layer') if k in cfg})
+    # probe at a small batch, then the largest power-of-two batch <= max_batch whose 2 + 5 steps fit what is left of the budget
+    progress('cpu baseline: cfg 1 %.3f s/step; probing the %s at batch %d' % (s1, label.split(' (')[0], probe_batch))
+    probe, _ = _cpu_train_steps(ocfg2, probe_batch, 1, 1, 1234, time.perf_counter() + 60.0)
     left = budget_s - (time.perf_counter() - t_start)
-    B = 64
-    while B > 8 and 7 * probe * (B / 8.0) * 0.8 > left:        # (x0.8: larger batches run the cores more efficiently)
+    B = max_batch
+    while B > probe_batch and 7 * probe * (B / float(probe_batch)) * 0.8 > left:        # (x0.8: larger batches run the cores more efficiently)
         B //= 2
-    progress('cpu baseline: %.2f s/step at batch 8; timing batch %d' % (probe, B))
-    s2, n2 = _cpu_train_steps(ocfg2, B, 2, 5, 1234, time.perf_counter() + max(left, 5.0) * 1.5)
+    progress('cpu baseline: %.2f s/step at batch %d; timing batch %d' % (probe, probe_batch, B))
+    s2, n2 = _cpu_train_steps(ocfg2, B, 2 if B > probe_batch else 1, 5, 1234, time.perf_counter() + max(left, 5.0) * 1.5)
     return dict(value=round(B / s2, 3), unit='images/sec', cores=int(cores), kind='port',
                 sample='torch-CPU fp32 restatement of the reference graph (tests/torch_ref.py: fwd + autograd bwd + Paddle-form Adam), '
-                       'NOT PaddlePaddle; bench workload (ResNet-50, 224x224, V 10000, L 20) at batch %d: %d timed steps after 2 warm-up, '
-                       '%.2f s/step; %.1f s of CPU work in all' % (B, n2, s2, time.perf_counter() - t_start),
+                       'NOT PaddlePaddle; %s at batch %d: %d timed steps after warm-up, '
+                       '%.2f s/step; %.1f s of CPU work in all' % (label, B, n2, s2, time.perf_counter() - t_start),
                 cfg1=dict(value=round(4 / s1, 2), unit='images/sec', sample='BASELINE cfg 1 (repo-default MobileNetV2 + 1024/256 decoder, 64x64, '
                           'V 1000, L 10, batch 4, singleton attention): %d timed steps after 2 warm-up, %.3f s/step' % (n1, s1)))
 
@@ -219,7 +220,9 @@ def extras(eng, cfg, B, image_d, cap_d, dev, steps=10):
         for _ in range(n):
             e.train_step(image_d, cap_d)
         torch.cuda.synchronize()
-        return round(B * n / (time.perf_counter() - t0), 1)
+        dt = time.perf_counter() - t0
+        e.check_sync()
+        return round(B * n / dt, 1)
     first = {}
     for key, over in (('bf16_slots', {}), ('bf16_singleton_attention', dict(attention='singleton')), ('f32_slots', dict(dtype='f32'))):
         progress('extra: ' + key)
@@ -237,25 +240,24 @@ def extras(eng, cfg, B, image_d, cap_d, dev, steps=10):
     return res
 
 
-def decode_bench(args):
-    """BASELINE configs[4] (`--decode`): the infer.py path (/root/reference/ImageCaptioning/infer.py:26-36 runs the saved
-    GREEDY graph on one image; beam search is this build's extension) at batch 128, beam 5, 224x224, ResNet-50 + 512-d
-    decoder, bf16, `is_test` batch norm as in the exported inference model.  One step = one batch decoded (encoder +
-    Ti = 20 decoder steps + backtrack), replayed from a hipGraph; prints captions/sec and the p50 latency of a batch."""
+def decode_measure(B, beam, steps, warmup, use_graph=True):
+    """BASELINE configs[4]: the infer.py path (/root/reference/ImageCaptioning/infer.py:26-36 runs the saved GREEDY graph on
+    one image; beam search is this build's extension) at batch B, 224x224, ResNet-50 + 512-d decoder, bf16, `is_test`
+    batch norm as in the exported inference model.  One step = one batch decoded (encoder + Ti = 20 decoder steps +
+    backtrack), replayed from a hipGraph.  Returns captions/sec and the p50 / p90 latency of a batch."""
     import torch
     from myimagecaptioningmodel_amd import default_cfg
     from myimagecaptioningmodel_amd.model import CaptionEngine
-    B, beam = args.batch or 128, args.beam
     cfg = default_cfg(batch_size=B, sample_count=0, **WORKLOAD)
-    eng = CaptionEngine(cfg, device='cuda:0', use_graph=not args.no_graph)
+    eng = CaptionEngine(cfg, device='cuda:0', use_graph=use_graph)
     image, _ = synthetic_batch(B, cfg, 1234)
     image_d = torch.as_tensor(image).to('cuda:0')
-    for _ in range(max(2, args.warmup)):          # call 1 warms up + captures, later calls replay
+    for _ in range(max(2, warmup)):          # call 1 warms up + captures, later calls replay
         ids = eng.decode(image_d, beam=beam, is_test=True)
     torch.cuda.synchronize()
     lat = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         t1 = time.perf_counter()
         ids = eng.decode(image_d, beam=beam, is_test=True)
         torch.cuda.synchronize()
@@ -264,14 +266,57 @@ def decode_bench(args):
     ids = ids.cpu().numpy()
     assert ids.shape == (B, cfg['infer_max_length']) and ((ids >= 0) & (ids < cfg['vocab'])).all()
     lat.sort()
-    out = {'metric': 'decode captions/sec (224x224, beam=%d, batch %d)' % (beam, B), 'value': round(B * args.steps / dt, 1), 'unit': 'captions/sec',
-           'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-           'p50_latency_ms': round(lat[len(lat) // 2] * 1e3, 3), 'p90_latency_ms': round(lat[int(len(lat) * 0.9)] * 1e3, 3),
+    del eng
+    torch.cuda.empty_cache()
+    return dict(captions_per_sec=round(B * steps / dt, 1), ms_per_batch=round(dt / steps * 1e3, 3),
+                p50_latency_ms=round(lat[len(lat) // 2] * 1e3, 3), p90_latency_ms=round(lat[int(len(lat) * 0.9)] * 1e3, 3),
+                batch=B, beam=beam, steps=steps)
+
+
+def decode_bench(args):
+    """`--decode`: BASELINE configs[4] as its own JSON line."""
+    B, beam = args.batch or 128, args.beam
+    m = decode_measure(B, beam, args.steps, args.warmup, use_graph=not args.no_graph)
+    out = {'metric': 'decode captions/sec (224x224, beam=%d, batch %d)' % (beam, B), 'value': m['captions_per_sec'], 'unit': 'captions/sec',
+           'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': m['ms_per_batch'],
+           'p50_latency_ms': m['p50_latency_ms'], 'p90_latency_ms': m['p90_latency_ms'],
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
            'config': {'workload': 'BASELINE configs[4]: infer.py path, ResNet-50 (build-defined) + 512-d decoder, vocab 10000, 224x224, '
                                   'Ti 20, beam %d (build-defined; beam 1 = the reference greedy loop), is_test batch norm, random-init weights' % beam,
                       'batch': B, 'beam': beam, 'launch': 'hipGraph replay of a single-lane plan' if not args.no_graph else 'capmi_plan_run, eager'}}
     print(json.dumps(out), flush=True)
+
+
+def config3_measure(dev, steps=4, warmup=2):
+    """BASELINE configs[3] at its full per-GPU size (ResNet-101 + 2-layer 1024-d LSTM decoder, 384x384, L 30, V 20 000, 64
+    images) as an `extra` of the default run: ms/step, images/s and the whole-step MFMA fraction with SURVEY.md 8(d)'s
+    149.9 GFLOP per image."""
+    import torch
+    from myimagecaptioningmodel_amd import default_cfg, profiling
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+    B = PER_GPU_BATCH
+    cfg = default_cfg(batch_size=B, sample_count=0, **WORKLOAD_CFG3)
+    eng = CaptionEngine(cfg, device=dev, use_graph=True)
+    image, cap = synthetic_batch(B, cfg, 1234)
+    image_d, cap_d = torch.as_tensor(image).to(dev), torch.as_tensor(cap).to(dev)
+    for _ in range(warmup):
+        loss, _ = eng.train_step(image_d, cap_d)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, _ = eng.train_step(image_d, cap_d)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.check_sync()
+    final = float(loss.cpu()[0])
+    assert final == final, 'configs[3]: loss is NaN'
+    rate = B * steps / dt
+    del eng
+    torch.cuda.empty_cache()
+    return dict(images_per_sec=round(rate, 1), ms_per_step=round(dt / steps * 1e3, 3), steps=steps, warmup=warmup, per_gpu_batch=B,
+                model_mfma_frac=round(rate * FLOPS_PER_IMAGE[3] / (profiling.PEAK_MFMA_TFLOPS['bf16'] * 1e12), 4),
+                final_loss=round(final, 4),
+                workload='BASELINE configs[3]: ResNet-101 (build-defined) + 2-layer 1024-d LSTM decoder, 384x384, seq_len 30, vocab 20000, 64 images per GPU, bf16')
 
 
 def main():
@@ -311,8 +356,8 @@ def main():
     torch.cuda.set_device(local)
     B = args.batch or PER_GPU_BATCH
     workload = WORKLOAD_CFG3 if args.config == 3 else WORKLOAD
-    if args.config == 3:            # extra mode: its own metric line, no roofline / extras / CPU baseline (those describe the bench workload)
-        args.no_roofline = args.no_extras = args.no_cpu_baseline = True
+    # (--config 3 is an extra mode: its own metric line, with its own roofline and CPU baseline; the `extra` block -- the
+    # bench workload's variants -- belongs to the default line only)
     cfg = default_cfg(batch_size=B * world, sample_count=0, **workload)
     eng = CaptionEngine(cfg, device=dev, use_graph=not args.no_graph, process_group=pg)
     trainer = dp.OverlappedTrainer(eng) if pg is not None else None      # (CAPMI_FORCE_DP=1: the N > 1 path on one rank)
@@ -346,6 +391,7 @@ def main():
         dt = float(t.item())
     final_loss = float(loss.cpu()[0])
     assert final_loss == final_loss, 'loss is NaN'           # the check of train.py:140-141
+    eng.check_sync()            # a grid barrier of the persistent recurrence that timed out anywhere in the loop voids the number
 
     out = None
     if rank == 0:
@@ -399,12 +445,24 @@ def main():
                                             'MB': round(s['bytes'] / s['launches'] / 1e6, 3)})
         out['roofline'] = roof
         out['kernel_breakdown_ms_per_step'] = {k: round(v['ms'] / 2, 3) for k, v in top[:8]}
-        flops_img = 26.18e9          # 6 x 4.363 GMAC fwd, GEMM-class ops only
+        flops_img = FLOPS_PER_IMAGE[args.config]          # 6 x forward GEMM-class MACs
         out['model_mfma_frac'] = round(out['value'] * flops_img / (world * profiling.PEAK_MFMA_TFLOPS['bf16'] * 1e12), 4)
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and args.config == 1:
         out['extra'] = extras(eng, cfg, B, image_d, cap_d, dev)
+        # BASELINE configs[3] and configs[4] in the record the driver writes (the headline above is untouched: its engine,
+        # timed region, workload and dtype are as before; these run after it)
+        del eng
+        torch.cuda.empty_cache()
+        progress('extra: config3 (ResNet-101 + 2-layer 1024-d LSTM, 384x384)')
+        out['extra']['config3'] = config3_measure(dev)
+        progress('extra: decode_beam5 (batch 128)')
+        out['extra']['decode_beam5'] = decode_measure(128, 5, 10, 2)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline(cfg)
+        if args.config == 3:
+            out['cpu_baseline'] = cpu_baseline(cfg, budget_s=40.0, probe_batch=1, max_batch=4,
+                                               label='BASELINE configs[3] workload (ResNet-101 + 2-layer 1024-d LSTM, 384x384, V 20000, L 30)')
+        else:
+            out['cpu_baseline'] = cpu_baseline(cfg)
     if rank == 0:
         sys.stdout.flush()
         os.dup2(real_stdout, 1)

@@ -30,6 +30,17 @@ enum { CAPMI_ACT_NONE = 0, CAPMI_ACT_RELU = 1, CAPMI_ACT_RELU6 = 2, CAPMI_ACT_TA
 int capmi_version(void);
 const char* capmi_last_error(void);
 
+/* Deterministic mode (verification; default off, or CAPMI_DETERMINISTIC=1 in the environment).  Paddle's executor gives
+ * no run-to-run guarantee either (IC/train.py:121-124 runs cuDNN / atomics underneath); this switch exists so that the
+ * build can PROVE schedule-independence: with it on, every f32 atomic accumulation of the library -- weight-gradient
+ * split-K on sub-tile outputs (capmi_igemm_tn_wgrad), the embedding scatter (capmi_embedding_bwd), bias column sums
+ * (capmi_colsum, capmi_dwconv3x3_bwd_weight) and the attention's d fc_10 (capmi_ada_attention_bwd) -- becomes a
+ * fixed-order reduction, and two runs of one launch sequence are bit-identical whatever the lanes' relative timing.
+ * Slower (single-pass column sums, slab reductions for every split weight gradient); capmi_ada_attention_bwd then uses
+ * a library-owned scratch buffer per device, so its deterministic launches must not overlap on one device. */
+int capmi_deterministic(void);
+int capmi_set_deterministic(int on);
+
 /* Alternates.  Four entry points are NOT on the default launch plans: each is a fused form that measured slower than
  * the launches it replaces on the ResNet-50 workload, is kept because it is the faster form at other sizes or the
  * per-step fallback of a fused kernel, and is covered by the same parity tests as the default path:
@@ -176,7 +187,12 @@ int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, 
  *                writes saved_mean, saved_invstd, coef_a = scale*invstd, and updates the running
  *                stats with momentum (run = m*run + (1-m)*batch)
  *                (more than 64 parts: a merge level first -- in the same launch, its last-arriving workgroup
- *                finalizes; library-owned arrival counters, nothing for the caller to provide or zero)
+ *                finalizes; library-owned arrival counters, nothing for the caller to provide or zero.
+ *                CONCURRENCY CONTRACT: the counters come from a per-device pool of 128 sets used round-robin in
+ *                host call order, so at most 127 LATER capmi_bn_finalize launches of this fused form may be in
+ *                flight on a device next to one that has not finished -- on any number of streams.  A caller that
+ *                cannot bound that sets CAPMI_BN_FUSE_MERGE=0, or captures the launch in a hipGraph: both take the
+ *                two-kernel merge -> finalize path, which has no shared state.)
  *   bn_apply   : y = act(coef_a*(x - mean) + offset (+ res))   (mean subtracted first: a*x + b
  *                with b = offset - a*mean would cancel when |mean| >> std)
  *   bn_bwd_reduce: with dz = dy * act'(y): red[0..C) += sum dz, red[C..2C) += sum dz*xhat; two
@@ -344,6 +360,10 @@ int capmi_beam_backtrack(const int* tokens, const int* parents, float* out_ids_f
  * grad_scale multiplies g first (1/N of ParallelExecutor's CoeffNumDevice, IC/train.py:121-124). */
 int capmi_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1,
                float b2, float eps, float clip, float grad_scale, void* stream);
+/* capmi_adam with the gradient read from a bf16 buffer (widened to f32 on load): the consumer of a bucket that was
+ * all-reduced in bf16 (capmi_allreduce_bucket_bf16).  Moments and master weights stay f32. */
+int capmi_adam_g16(float* p, const void* g16, float* m, float* v, int64_t n, float lr_t, float b1,
+                   float b2, float eps, float clip, float grad_scale, void* stream);
 /* Weight shadows for the MFMA kernels: capmi_cast = elementwise f32 -> `dtype`;
  * capmi_weight_dgrad_form: W [N][kh][kw][C] f32 -> the data-gradient operand [C][kh][kw][ldt]
  * (taps flipped; columns N..ldt zero; ldt > N only for 1x1 weights). */
@@ -373,6 +393,10 @@ int capmi_comm_unique_id(void* id_out);
 int capmi_comm_init(void** comm, int nranks, int rank, const void* id);
 int capmi_comm_destroy(void* comm);
 int capmi_allreduce_bucket(void* comm, float* buf, int64_t n, void* stream);
+/* The same on a bf16 copy of the bucket (capmi_cast of the f32 gradients into a staging buffer; capmi_adam_g16 reads the sum
+ * back): half the xGMI bytes -- SURVEY.md section 8(e) budgets the exchange in bf16 (73 MB at BASELINE cfg 2).  The ring
+ * rounds every partial sum to bf16; the f32 form above is the reference-precision path. */
+int capmi_allreduce_bucket_bf16(void* comm, void* buf16, int64_t n, void* stream);
 
 /* Launch plans.  A train step is a fixed sequence of ~650 of the entry points above on a few HIP streams ("lanes":
  * 0 = the dependency chain, 1 = weight gradients and other off-chain work, 2 = communication + optimizer).  The host

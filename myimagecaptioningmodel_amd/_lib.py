@@ -88,11 +88,13 @@ SIGNATURES = {
     'capmi_softmax_xent_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'capmi_argmax': [_p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_adam': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
+    'capmi_adam_g16': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
     'capmi_cast': [_p, _p, _l, _i, _p],
     'capmi_weight_dgrad_form': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'capmi_weight_dgrad_form_batched': [_p, _p, _p, _i, _i, _p],
     'capmi_fill_f32': [_p, _f, _l, _p],
     'capmi_allreduce_bucket': [_p, _p, _l, _p],
+    'capmi_allreduce_bucket_bf16': [_p, _p, _l, _p],
 }
 
 
@@ -108,6 +110,8 @@ QUERIES = {
     'capmi_lstm_step_supported': [_i, _i, _i],
     'capmi_lstm_seq_supported': [_i, _i, _i, _i],
     'capmi_bn_bwd_ws_floats': [_i, _i, _i],
+    'capmi_deterministic': [],
+    'capmi_set_deterministic': [_i],
 }
 
 # lane synchronisation (no stream-last convention): name -> argument ctypes
@@ -190,6 +194,15 @@ def lib():
 
 def last_error():
     return lib().capmi_last_error().decode()
+
+
+def set_deterministic(on):
+    """capmi_set_deterministic (include/capmi.h): fixed-order reductions in place of every f32 atomic accumulation, so that
+    runs of one launch sequence are bit-identical whatever the lanes' timing.  Returns the previous setting."""
+    L = lib()
+    prev = bool(L.capmi_deterministic())
+    L.capmi_set_deterministic(1 if on else 0)
+    return prev
 
 
 def call(name, *args):

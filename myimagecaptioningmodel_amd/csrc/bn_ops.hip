@@ -220,16 +220,24 @@ __global__ __launch_bounds__(256) void bn_merge_finalize_kernel(const float* __r
                            update_running, red);
 }
 
-// Arrival counters of bn_merge_finalize_kernel: a pool of 128 sets of 32 (one counter per 64-channel block, C <= 2048),
-// handed out round-robin per launch and zero again when a launch ends.  Two launches share a set only when they are 128
-// launches apart in host order -- more than two training steps -- and the lanes of a step are joined at its end, so they
-// never run at the same time.
+// Arrival counters of bn_merge_finalize_kernel: a pool of 128 sets of 32 per DEVICE (one counter per 64-channel block,
+// C <= 2048), handed out round-robin per launch and zero again when a launch ends.  Contract (capmi.h): two launches share
+// a set only when they are 128 capmi_bn_finalize calls apart in host order on that device, so the caller must not keep
+// more than 127 later fused launches in flight next to an unfinished one -- the engine joins its lanes at the end of every
+// step (< 60 such launches per step).  The symbol's address differs per device: it is looked up once per device.
 __device__ unsigned bn_arrival_counters[128 * 32];
 static unsigned* next_arrival_counters() {
-    static std::atomic<unsigned> next{0};
-    static unsigned* base = nullptr;
-    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(bn_arrival_counters)) != hipSuccess) return nullptr;
-    return base + (next.fetch_add(1) % 128u) * 32u;
+    constexpr int MAXDEV = 64;
+    static std::atomic<unsigned> next[MAXDEV];
+    static std::atomic<unsigned*> base[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    unsigned* b = base[dev].load(std::memory_order_acquire);
+    if (!b) {
+        if (hipGetSymbolAddress((void**)&b, HIP_SYMBOL(bn_arrival_counters)) != hipSuccess || !b) return nullptr;
+        base[dev].store(b, std::memory_order_release);
+    }
+    return b + (next[dev].fetch_add(1) % 128u) * 32u;
 }
 
 #define CAPMI_BN_MERGE_GROUPS 32     // merged groups (64 for C <= 128: few channel blocks, so more row groups); ws has room for 64 extra parts (capmi.h)

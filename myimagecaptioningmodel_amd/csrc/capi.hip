@@ -1,5 +1,6 @@
 // Error reporting + version of libcapmi.so.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -12,6 +13,23 @@ extern "C" void capmi_set_error(const char* fmt, ...) {
 }
 extern "C" const char* capmi_last_error(void) { return g_err; }
 extern "C" int capmi_version(void) { return CAPMI_ABI_VERSION; }
+
+// ------------------------------------------------------------------ deterministic mode (verification)
+// CAPMI_DETERMINISTIC=1 (or capmi_set_deterministic(1)): every f32 atomic accumulation of the library -- weight-gradient
+// split-K on sub-tile outputs, the embedding scatter, bias column sums, the attention's d fc_10 -- is replaced by a
+// fixed-order reduction, so that two runs of the same launch sequence are bit-identical whatever the lanes' timing.
+static int g_deterministic = -1;
+extern "C" int capmi_deterministic(void) {
+    if (g_deterministic < 0) {
+        const char* e = getenv("CAPMI_DETERMINISTIC");
+        g_deterministic = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return g_deterministic;
+}
+extern "C" int capmi_set_deterministic(int on) {
+    g_deterministic = on ? 1 : 0;
+    return 0;
+}
 
 // ------------------------------------------------------------------ lane synchronisation
 // Device-scope events for ordering two HIP streams of the SAME device (plan lanes).  Created without

@@ -36,11 +36,31 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __res
     if (id == padding_idx || id < 0 || id >= V) return;
     atomicAdd(&dtable[id * E + j], to_f32(dout[(int64_t)m * ldo + j]));
 }
+// Deterministic form (capmi_deterministic): workgroup m owns table row ids[m] iff m is the FIRST row with that id; the
+// owner adds the rows m, m' > m, ... with the same id in increasing row order and is the only writer of its table row.
+template <typename T>
+__global__ __launch_bounds__(256) void embedding_bwd_det_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout, float* dtable,
+                                                                int M, int E, int V, int ldo, int padding_idx) {
+    const int m = blockIdx.x;
+    const int64_t id = ids[m];
+    if (id == padding_idx || id < 0 || id >= V) return;
+    for (int p = 0; p < m; ++p)
+        if (ids[p] == id) return;               // an earlier row owns this id (uniform branch: ids are read by every lane alike)
+    for (int j = threadIdx.x; j < E; j += 256) {
+        float acc = to_f32(dout[(int64_t)m * ldo + j]);
+        for (int p = m + 1; p < M; ++p)
+            if (ids[p] == id) acc += to_f32(dout[(int64_t)p * ldo + j]);
+        dtable[id * E + j] += acc;
+    }
+}
 extern "C" int capmi_embedding_bwd(const int64_t* ids, const void* dout, float* dtable, int M, int E, int V, int ldo,
                                    int padding_idx, int dtype, void* stream) {
     CAPMI_CHECK(ids && dout && dtable, "capmi_embedding_bwd: null pointer");
     CAPMI_DISPATCH(dtype, "capmi_embedding_bwd", {
-        hipLaunchKernelGGL(embedding_bwd_kernel<T>, dim3(cdiv((int64_t)M * E, 256)), dim3(256), 0, (hipStream_t)stream, ids, (const T*)dout, dtable, M, E, V, ldo, padding_idx);
+        if (capmi_deterministic())
+            hipLaunchKernelGGL(embedding_bwd_det_kernel<T>, dim3(M), dim3(256), 0, (hipStream_t)stream, ids, (const T*)dout, dtable, M, E, V, ldo, padding_idx);
+        else
+            hipLaunchKernelGGL(embedding_bwd_kernel<T>, dim3(cdiv((int64_t)M * E, 256)), dim3(256), 0, (hipStream_t)stream, ids, (const T*)dout, dtable, M, E, V, ldo, padding_idx);
     });
     CAPMI_LAUNCH_CHECK("capmi_embedding_bwd");
     return 0;
@@ -378,7 +398,7 @@ extern "C" int capmi_ada_attention_fwd(const void* Ve, const void* Vt, const voi
 // slots backward, phase 1 (workgroup per row m): dalpha, de, ds, db10.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_slots_bwd1_kernel(const T* __restrict__ Vt, const T* __restrict__ s, const float* __restrict__ alpha,
-                                                              const T* __restrict__ dout, T* ds, float* de, float* db10, int B, int K, int H) {
+                                                              const T* __restrict__ dout, T* ds, float* de, float* db10, float* det_db, int B, int K, int H) {
     constexpr int VEC = Vec<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [K+1] dalpha | [16] scratch
     float* da = smem;
@@ -410,7 +430,10 @@ __global__ __launch_bounds__(256) void attn_slots_bwd1_kernel(const T* __restric
         dsum += d;
     }
     dsum = block_sum(dsum, scratch);
-    if (tid == 0) atomicAdd(db10, dsum);
+    if (tid == 0) {
+        if (det_db) det_db[m] = dsum;           // deterministic mode: per-row partial, summed in row order by attn_det_finish_kernel
+        else atomicAdd(db10, dsum);
+    }
     const float aK = alpha[(int64_t)m * (K + 1) + K] * inv;
     for (int cc = tid; cc < cpr; cc += 256) {
         Vec<T> d = vload<T>(dout + (int64_t)m * H + cc * VEC), ov;
@@ -427,7 +450,7 @@ __global__ __launch_bounds__(256) void attn_slots_bwd1_kernel(const T* __restric
 template <typename T, int MAXK>
 __global__ __launch_bounds__(256) void attn_slots_bwd2_kernel(const T* __restrict__ Ve, const T* __restrict__ q, const T* __restrict__ se,
                                                               const T* __restrict__ w10, const float* __restrict__ alpha, const float* __restrict__ de,
-                                                              const T* __restrict__ dout, T* dVt, T* dVe, T* dq, T* dse, float* dw10,
+                                                              const T* __restrict__ dout, T* dVt, T* dVe, T* dq, T* dse, float* dw10, float* det_dw,
                                                               int T_, int B, int K, int H) {
     constexpr int VEC = Vec<T>::N;
     constexpr int TH = 8, KG = 256 / TH;
@@ -552,8 +575,29 @@ __global__ __launch_bounds__(256) void attn_slots_bwd2_kernel(const T* __restric
     __syncthreads();
     if (kg == 0 && cok) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v)
-            atomicAdd(&dw10[chunk * VEC + v], sdw[0][cc * VEC + v] + sdw[1][cc * VEC + v] + sdw[2][cc * VEC + v] + sdw[3][cc * VEC + v]);
+        for (int v = 0; v < VEC; ++v) {
+            const float part = sdw[0][cc * VEC + v] + sdw[1][cc * VEC + v] + sdw[2][cc * VEC + v] + sdw[3][cc * VEC + v];
+            if (det_dw) det_dw[(int64_t)b * H + chunk * VEC + v] = part;      // deterministic mode: per-image partial
+            else atomicAdd(&dw10[chunk * VEC + v], part);
+        }
+    }
+}
+
+// Deterministic mode (capmi_deterministic): d b10 += sum_m det_db[m] (row order), d w10[h] += sum_b det_dw[b][h] (image order).
+constexpr int ATTN_DET_FLOATS = 1 << 19;
+__device__ float attn_det_scratch[ATTN_DET_FLOATS];
+__global__ __launch_bounds__(256) void attn_det_finish_kernel(const float* __restrict__ det_db, int M, const float* __restrict__ det_dw, int B, int H,
+                                                              float* db10, float* dw10) {
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h < H) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) acc += det_dw[(int64_t)b * H + h];
+        dw10[h] += acc;
+    }
+    if (h == 0) {
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += det_db[m];
+        *db10 += acc;
     }
 }
 
@@ -573,14 +617,23 @@ extern "C" int capmi_ada_attention_bwd(const void* Ve, const void* Vt, const voi
             constexpr int TH = 8;
             CAPMI_CHECK(K <= 8 * (256 / TH), "capmi_ada_attention_bwd: K=%d above the supported %d", K, 8 * (256 / TH));
             size_t sh = (size_t)(K + 1 + 16) * sizeof(float);
-            hipLaunchKernelGGL(attn_slots_bwd1_kernel<T>, dim3(T_ * B), dim3(256), sh, (hipStream_t)stream, (const T*)Vt, (const T*)s, alpha, (const T*)dout, (T*)ds, de, db10, B, K, H);
+            float* det_db = nullptr;
+            float* det_dw = nullptr;
+            if (capmi_deterministic()) {        // library-owned scratch of the current device: [T*B] d b10 partials | [B][H] d w10 partials
+                CAPMI_CHECK((long long)T_ * B + (long long)B * H <= ATTN_DET_FLOATS, "capmi_ada_attention_bwd: T*B + B*H above the deterministic scratch (%d floats)", ATTN_DET_FLOATS);
+                CAPMI_CHECK(hipGetSymbolAddress((void**)&det_db, HIP_SYMBOL(attn_det_scratch)) == hipSuccess && det_db, "capmi_ada_attention_bwd: no deterministic scratch");
+                det_dw = det_db + (size_t)T_ * B;
+            }
+            hipLaunchKernelGGL(attn_slots_bwd1_kernel<T>, dim3(T_ * B), dim3(256), sh, (hipStream_t)stream, (const T*)Vt, (const T*)s, alpha, (const T*)dout, (T*)ds, de, db10, det_db, B, K, H);
             int tiles = cdiv(cpr, TH);
             if (K <= 2 * (256 / TH))
                 hipLaunchKernelGGL((attn_slots_bwd2_kernel<T, 2>), dim3(B * tiles), dim3(256), 0, (hipStream_t)stream, (const T*)Ve, (const T*)q, (const T*)se,
-                                   (const T*)w10, alpha, de, (const T*)dout, (T*)dVt, (T*)dVe, (T*)dq, (T*)dse, dw10, T_, B, K, H);
+                                   (const T*)w10, alpha, de, (const T*)dout, (T*)dVt, (T*)dVe, (T*)dq, (T*)dse, dw10, det_dw, T_, B, K, H);
             else
                 hipLaunchKernelGGL((attn_slots_bwd2_kernel<T, 8>), dim3(B * tiles), dim3(256), 0, (hipStream_t)stream, (const T*)Ve, (const T*)q, (const T*)se,
-                                   (const T*)w10, alpha, de, (const T*)dout, (T*)dVt, (T*)dVe, (T*)dq, (T*)dse, dw10, T_, B, K, H);
+                                   (const T*)w10, alpha, de, (const T*)dout, (T*)dVt, (T*)dVe, (T*)dq, (T*)dse, dw10, det_dw, T_, B, K, H);
+            if (det_db)
+                hipLaunchKernelGGL(attn_det_finish_kernel, dim3(cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, det_db, T_ * B, det_dw, B, H, db10, dw10);
         }
     });
     CAPMI_LAUNCH_CHECK("capmi_ada_attention_bwd");
@@ -1001,7 +1054,8 @@ extern "C" int capmi_beam_backtrack(const int* tokens, const int* parents, float
 }
 
 // ------------------------------------------------------------------ column sums (bias gradients)
-template <typename T>
+// DET (capmi_deterministic): one row block per column block, row lanes folded in lane order, a single writer per column.
+template <typename T, bool DET>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, int M, int N, int lda, float* out, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
     __shared__ float s1[256 * VEC];
@@ -1010,10 +1064,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, in
     __syncthreads();
     const int cc = tid % L.cpc, rr = tid / L.cpc;
     const int chunk = blockIdx.y * L.cpc + cc;
-    if (rr < L.rp && chunk * VEC < N) {
-        float acc[VEC];
+    const bool active = rr < L.rp && chunk * VEC < N;
+    float acc[VEC];
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+    if (active) {
         const int m_begin = blockIdx.x * L.rows_per_block;
         const int m_end = min(M, m_begin + L.rows_per_block);
         for (int m = m_begin + rr; m < m_end; m += L.rp) {
@@ -1021,13 +1076,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ a, in
 #pragma unroll
             for (int v = 0; v < VEC; ++v) acc[v] += x.get(v);
         }
+        if constexpr (!DET) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) atomicAdd(&s1[cc * VEC + v], acc[v]);
+            for (int v = 0; v < VEC; ++v) atomicAdd(&s1[cc * VEC + v], acc[v]);
+        }
+    }
+    if constexpr (DET) {
+        for (int r = 0; r < L.rp; ++r) {
+            if (active && rr == r) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) s1[cc * VEC + v] += acc[v];
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
     for (int i = tid; i < L.cpc * VEC; i += 256) {
         int c = blockIdx.y * L.cpc * VEC + i;
-        if (c < N) atomicAdd(&out[c], s1[i]);
+        if (c < N) {
+            if constexpr (DET) out[c] += s1[i];
+            else atomicAdd(&out[c], s1[i]);
+        }
     }
 }
 extern "C" int capmi_colsum(const void* a, int M, int N, int lda, float* out, int dtype, void* stream) {
@@ -1037,7 +1106,12 @@ extern "C" int capmi_colsum(const void* a, int M, int N, int lda, float* out, in
         CAPMI_CHECK(lda % VEC == 0 && lda >= (N + VEC - 1) / VEC * VEC, "capmi_colsum: lda=%d must be a multiple of %d covering N=%d", lda, VEC, N);
         int gx, gy;
         ColLayout L = col_layout(M, (N + VEC - 1) / VEC * VEC, VEC, &gx, &gy);
-        hipLaunchKernelGGL(colsum_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)a, M, N, lda, out, L);
+        if (capmi_deterministic()) {
+            L.rows_per_block = M;
+            hipLaunchKernelGGL((colsum_kernel<T, true>), dim3(1, gy), dim3(256), 0, (hipStream_t)stream, (const T*)a, M, N, lda, out, L);
+        } else {
+            hipLaunchKernelGGL((colsum_kernel<T, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)a, M, N, lda, out, L);
+        }
     });
     CAPMI_LAUNCH_CHECK("capmi_colsum");
     return 0;

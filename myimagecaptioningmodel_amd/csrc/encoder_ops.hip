@@ -317,7 +317,9 @@ extern "C" int capmi_dwconv3x3_bwd_data(const void* dy, const void* w, void* dx,
 }
 
 // dw[r][q][c] += sum over output pixels dy[p][c] * x[p*stride + tap][c]
-template <typename T>
+// DET (capmi_deterministic): ONE row block per column block (gridDim.x == 1), the row lanes' partials are folded into LDS
+// in lane order and the block total is added by its only writer -- no atomics, fixed summation order.
+template <typename T, bool DET>
 __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* dw, int B, int Hi, int Wi,
                                                                 int C, int stride, int Ho, int Wo, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
@@ -329,12 +331,12 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
     const int cc = tid % L.cpc, rr = tid / L.cpc;
     const int chunk = blockIdx.y * L.cpc + cc;
     const bool active = rr < L.rp && chunk < cpr;
+    float acc[9][VEC];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[t][v] = 0.f;
     if (active) {
-        float acc[9][VEC];
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[t][v] = 0.f;
         const int M = B * Ho * Wo;
         const int m_begin = blockIdx.x * L.rows_per_block;
         const int m_end = min(M, m_begin + L.rows_per_block);
@@ -356,16 +358,32 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const T* __restr
                 }
             }
         }
+        if constexpr (!DET) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) atomicAdd(&sacc[(t * L.cpc + cc) * VEC + v], acc[t][v]);
+                for (int v = 0; v < VEC; ++v) atomicAdd(&sacc[(t * L.cpc + cc) * VEC + v], acc[t][v]);
+        }
+    }
+    if constexpr (DET) {
+        for (int r = 0; r < L.rp; ++r) {
+            if (active && rr == r) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) sacc[(t * L.cpc + cc) * VEC + v] += acc[t][v];
+            }
+            __syncthreads();
+        }
     }
     __syncthreads();
     for (int i = tid; i < 9 * L.cpc * VEC; i += 256) {
         int t = i / (L.cpc * VEC), j = i % (L.cpc * VEC);
         int c = blockIdx.y * L.cpc * VEC + j;
-        if (c < C) atomicAdd(&dw[t * C + c], sacc[i]);
+        if (c < C) {
+            if constexpr (DET) dw[t * C + c] += sacc[i];
+            else atomicAdd(&dw[t * C + c], sacc[i]);
+        }
     }
 }
 extern "C" int capmi_dwconv3x3_bwd_weight(const void* x, const void* dy, float* dw, int B, int Hi, int Wi, int C, int stride,
@@ -375,7 +393,12 @@ extern "C" int capmi_dwconv3x3_bwd_weight(const void* x, const void* dy, float* 
         CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_dwconv3x3_bwd_weight: C not a multiple of the vector width");
         int gx, gy;
         ColLayout L = col_layout(B * Ho * Wo, C, Vec<T>::N, &gx, &gy, 64);
-        hipLaunchKernelGGL(dwconv_bwd_weight_kernel<T>, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, B, Hi, Wi, C, stride, Ho, Wo, L);
+        if (capmi_deterministic()) {
+            L.rows_per_block = B * Ho * Wo;
+            hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, true>), dim3(1, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, B, Hi, Wi, C, stride, Ho, Wo, L);
+        } else {
+            hipLaunchKernelGGL((dwconv_bwd_weight_kernel<T, false>), dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, dw, B, Hi, Wi, C, stride, Ho, Wo, L);
+        }
     });
     CAPMI_LAUNCH_CHECK("capmi_dwconv3x3_bwd_weight");
     return 0;

@@ -1349,9 +1349,13 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(const T* __restrict_
 // per step with them, against 10.9 for a kernel boundary.  `fences` != 0 adds them back (agent-scope release before the
 // arrival, acquire behind the poll; CAPMI_LSTM_SEQ=2).  Everything else a workgroup touches is either written before the
 // launch or written and re-read by the same thread.  Every handed-off row block is written exactly once per launch
-// before it is read.  Grids are <= 128 workgroups of 256 threads: always co-resident.  Every spin is bounded: after
+// before it is read.  Grids are <= 128 workgroups of 256 threads: they fit the chip at once, but they are co-resident only
+// once the side lane's (finite) weight-gradient kernels have let them in -- progress rests on those kernels draining, not on
+// an occupancy guarantee.  Every spin is bounded: after
 // SEQ_SPIN_LIMIT polls a workgroup sets sync[1] and runs on (later barriers see the flag and do not wait), so the launch
-// always drains; the host checks sync[1] (capmi_lstm_seq_* zero both words before the launch).
+// always drains.  sync[0] = arrival counter and sync[1] = "somebody gave up in THIS launch" are zeroed by capmi_lstm_seq_*
+// before every launch; sync[2] is STICKY: set together with sync[1], never cleared by the library -- the host reads and
+// clears it (DecoderRunner.check_sync), so a time-out in step N is still visible after steps N+1.. have been enqueued.
 constexpr unsigned SEQ_SPIN_LIMIT = 1u << 21;
 typedef unsigned int seq_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -1369,6 +1373,7 @@ __device__ __forceinline__ void seq_grid_barrier(unsigned* sync, unsigned target
             __builtin_amdgcn_s_sleep(1);
             if (++spins > SEQ_SPIN_LIMIT || __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
                 __hip_atomic_store(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sticky: only the host clears it
                 break;
             }
         }
@@ -1639,18 +1644,25 @@ extern "C" int capmi_lstm_seq_supported(int B, int H, int T, int dtype) {
     return 0;
 }
 static int seq_sync_reset(void* sync, hipStream_t st, const char* who) {
-    hipError_t e = hipMemsetAsync(sync, 0, 16, st);
+    hipError_t e = hipMemsetAsync(sync, 0, 8, st);          // arrival counter + this launch's gave-up flag; word 2 (sticky) stays
     if (e != hipSuccess) {
         capmi_set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
         return 1;
     }
     return 0;
 }
-static int seq_fences() {      // CAPMI_LSTM_SEQ=2: agent-scope release / acquire fences around the arrival counter as well
+// CAPMI_LSTM_SEQ=2: agent-scope release / acquire fences around the arrival counter as well.  The fence-free hand-off
+// (write-through stores + sc1 loads) is outside the HIP memory model: it rests on gfx950's sc1 semantics
+// (MI355X_MICROARCH.md, inter-workgroup visibility), so it is the default ONLY where the current device reports gfx950;
+// anywhere else the fences stay in.
+static int seq_fences() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("CAPMI_LSTM_SEQ");
         v = (e && e[0] == '2') ? 1 : 0;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) v = 1;
     }
     return v;
 }
@@ -1848,13 +1860,17 @@ static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, b
 }
 
 // 3x3 / stride 1 / pad 1 "same" convolutions (forward, and the data gradient of one) on rows of <= 56 pixels, channels
-// in chunks of 32: the halo-staged kernel.  OFF by default (CAPMI_HALO3=1 enables it; 2 / 3: forward / data-gradient
-// calls only).  Status, round 2: bit-exact against torch and bit-reproducible when it runs alone (tools/halo_check*.py),
-// 1.15-1.4x faster than the kernels above on the res2-res4 3x3 layers, -0.07 to -0.15 ms per step in the model -- but
-// inside the two-lane train step its forward launches at 56x56 (BM = BN = 64) come out with a few 16-row strips slightly
-// wrong, differently every run, while another LDS-DMA kernel is resident on the other HIP stream: reproducible with
-// every wait replaced by vmcnt(0) (-DCAPMI_HALO_SAFE), gone with a host-side device synchronisation or an empty kernel
-// in front of the launch, or on a single stream.  Not understood; not shipped.
+// in chunks of 32: the halo-staged kernel, ON by default (CAPMI_HALO3=0 restores per-tap staging; 2 / 3: forward /
+// data-gradient calls only).  History (DESIGN.md lesson 29): alone it was bit-exact from the start, inside the two-lane
+// train step its 56x56 launches came out with a few 16-row strips wrong, differently every run.  Root cause: an LDS
+// write-after-read the source did not show -- the tap loop is unrolled and s_barrier is IntrNoMem, so the scheduler sank
+// the MFMAs of step s (and with them the lgkmcnt wait that retires the step's fragment reads) below the barrier and the
+// DMA issue of step s + 1, i.e. the ring slot was being refilled while its reads were not known to have returned.  Fix: the
+// sched_barrier(0) behind the last MFMA of every tap (see the kernel).  The fix depends on the compiler keeping the
+// lgkmcnt wait in FRONT of s_barrier, so two gates must stay green on every toolchain bump: tools/lds_war_audit.py (static
+// screen of the device assembly for an LDS-DMA issue behind a barrier with unretired ds_reads; tests/test_host.py runs
+// it when hipcc is present) and the in-situ check of all 53 / 104 convolutions inside the two-lane step
+// (tests/test_gpu_fullsize.py).
 static bool nt_halo3_ok(const IGemmArgs& a, const capmi_conv_geom* g, int nred) {
     static const int mode = getenv("CAPMI_HALO3") ? atoi(getenv("CAPMI_HALO3")) : 1;      // 0: per-tap staging; 2 / 3: forward / data-gradient calls only
     if (mode == 0 || (mode == 2 && !a.stats) || (mode == 3 && a.stats)) return false;
@@ -2418,7 +2434,7 @@ extern "C" long long capmi_igemm_tn_ws_bytes(int M, int N, int K, int dtype) {
     int bno, bko, per;
     tn_tile(N, K, dtype, &bno, &bko);
     const int splits = tn_splits(M, N, K, bno, bko, &per);
-    if (splits <= 1 || splits > 24 || bno < 128) return 0;
+    if (splits <= 1 || ((splits > 24 || bno < 128) && !capmi_deterministic())) return 0;
     return (long long)splits * cdiv(N, bno) * bno * cdiv(K, bko) * bko * 4;
 }
 
@@ -2435,7 +2451,9 @@ static int launch_tn(WGradArgs& a, float* ws, long long ws_bytes, hipStream_t st
     a.Kp = cdiv(a.K, BKO) * BKO;
     a.slab = nullptr;
     static const int force_atomic = getenv("CAPMI_TN_ATOMIC") ? atoi(getenv("CAPMI_TN_ATOMIC")) : 0;  // experiment knob
-    const bool use_slab = splits > 1 && splits <= 24 && BNO >= 128 && !force_atomic;   // many splits / tiny outputs: the slab reduce would be latency-bound
+    // many splits / tiny outputs: the slab reduce would be latency-bound -> f32 atomics, unless the deterministic mode asks
+    // for a fixed summation order (capmi.h): then every split product goes through the slabs
+    const bool use_slab = splits > 1 && ((splits <= 24 && BNO >= 128 && !force_atomic) || capmi_deterministic());
     if (use_slab) {
         CAPMI_CHECK(ws && ws_bytes >= (long long)splits * a.Np * a.Kp * 4, "capmi_igemm_tn_wgrad: workspace too small (%lld bytes needed)",
                     (long long)splits * a.Np * a.Kp * 4);

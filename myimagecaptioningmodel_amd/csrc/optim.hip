@@ -2,11 +2,19 @@
 // and the data-gradient weight form ([N][kh][kw][C] -> [C][kh][kw][N], taps flipped).
 #include "common.h"
 
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+// G = float: the flat f32 gradient buffer; G = bf16: a bucket that went through the all-reduce in bf16 (capmi_adam_g16).
+template <typename G> __device__ __forceinline__ f32x4 adam_load4(const G* g, int64_t i);
+template <> __device__ __forceinline__ f32x4 adam_load4<float>(const float* g, int64_t i) { return reinterpret_cast<const f32x4*>(g)[i]; }
+template <> __device__ __forceinline__ f32x4 adam_load4<bf16>(const bf16* g, int64_t i) {
+    const bf16x4 v = reinterpret_cast<const bf16x4*>(g)[i];
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename G>
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float lr_t, float b1, float b2, float eps, float clip, float gscale) {
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = adam_load4<G>(g, i);
         f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -22,7 +30,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         int64_t i = n4 * 4 + threadIdx.x;
-        float gg = g[i] * gscale;
+        float gg = to_f32(g[i]) * gscale;
         if (clip > 0.f) gg = fminf(fmaxf(gg, -clip), clip);
         float mm = b1 * m[i] + (1.f - b1) * gg, vv = b2 * v[i] + (1.f - b2) * gg * gg;
         m[i] = mm; v[i] = vv;
@@ -34,8 +42,19 @@ extern "C" int capmi_adam(float* p, const float* g, float* m, float* v, int64_t 
     CAPMI_CHECK(p && g && m && v, "capmi_adam: null pointer");
     CAPMI_CHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "capmi_adam: buffers must be 16-byte aligned");
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, b1, b2, eps, clip, grad_scale);
+    hipLaunchKernelGGL(adam_kernel<float>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, b1, b2, eps, clip, grad_scale);
     CAPMI_LAUNCH_CHECK("capmi_adam");
+    return 0;
+}
+/* The same update from a bf16 gradient bucket (the data-parallel step's all-reduce payload, capmi_allreduce_bucket_bf16):
+ * the gradient is widened to f32 on load, everything else -- moments, master weights, arithmetic -- is capmi_adam. */
+extern "C" int capmi_adam_g16(float* p, const void* g16, float* m, float* v, int64_t n, float lr_t, float b1, float b2, float eps,
+                              float clip, float grad_scale, void* stream) {
+    CAPMI_CHECK(p && g16 && m && v, "capmi_adam_g16: null pointer");
+    CAPMI_CHECK(((uintptr_t)p | (uintptr_t)m | (uintptr_t)v) % 16 == 0 && (uintptr_t)g16 % 8 == 0, "capmi_adam_g16: buffers must be 16-byte (gradient: 8-byte) aligned");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(adam_kernel<bf16>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, (const bf16*)g16, m, v, n, lr_t, b1, b2, eps, clip, grad_scale);
+    CAPMI_LAUNCH_CHECK("capmi_adam_g16");
     return 0;
 }
 

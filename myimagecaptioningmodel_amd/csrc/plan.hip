@@ -101,11 +101,13 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_gather_rows),
     CAPMI_ENTRY(capmi_beam_backtrack),
     CAPMI_ENTRY(capmi_adam),
+    CAPMI_ENTRY(capmi_adam_g16),
     CAPMI_ENTRY(capmi_cast),
     CAPMI_ENTRY(capmi_weight_dgrad_form),
     CAPMI_ENTRY(capmi_weight_dgrad_form_batched),
     CAPMI_ENTRY(capmi_fill_f32),
     CAPMI_ENTRY(capmi_allreduce_bucket),
+    CAPMI_ENTRY(capmi_allreduce_bucket_bf16),
 };
 constexpr int kEntries = sizeof(g_entries) / sizeof(g_entries[0]);
 
@@ -214,5 +216,14 @@ extern "C" int capmi_allreduce_bucket(void* comm, float* buf, int64_t n, void* s
     CAPMI_CHECK(buf, "capmi_allreduce_bucket: null buffer");
     ncclResult_t r = g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
     CAPMI_CHECK(r == ncclSuccess, "capmi_allreduce_bucket: %s", g_rccl.GetErrorString(r));
+    return 0;
+}
+
+extern "C" int capmi_allreduce_bucket_bf16(void* comm, void* buf16, int64_t n, void* stream) {
+    CAPMI_CHECK(comm && g_rccl.AllReduce, "capmi_allreduce_bucket_bf16: no communicator (capmi_comm_init first)");
+    if (n <= 0) return 0;
+    CAPMI_CHECK(buf16, "capmi_allreduce_bucket_bf16: null buffer");
+    ncclResult_t r = g_rccl.AllReduce(buf16, buf16, (size_t)n, ncclBfloat16, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
+    CAPMI_CHECK(r == ncclSuccess, "capmi_allreduce_bucket_bf16: %s", g_rccl.GetErrorString(r));
     return 0;
 }

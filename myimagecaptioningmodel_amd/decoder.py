@@ -49,8 +49,9 @@ class DecoderRunner:
         self.slots = 1 if slots else 0
         self.pad = cfg['padding_idx']
         self.L = int(cfg.get('rnn_layer', 1))
-        # grid-barrier state of the persistent recurrence kernels: 16 bytes per launch (layer x direction); word 1 of a
-        # slot is set when a barrier gave up waiting (check_sync)
+        # grid-barrier state of the persistent recurrence kernels: 16 bytes per launch slot (layer x direction).  Word 0 =
+        # arrival counter, word 1 = a barrier gave up in the launch in flight (both zeroed by the library per launch),
+        # word 2 = STICKY copy of word 1 that only check_sync clears: a time-out in any earlier step stays visible
         self.seq_sync = torch.zeros((2 * self.L, 4), dtype=torch.int32, device=store.device)
         self.use_seq = (self.seq_lstm and os.environ.get('CAPMI_LSTM_SEQ', '1') != '0'
                         and bool(lib().capmi_lstm_seq_supported(B, cfg['hidden'], T, dtype_code)))
@@ -94,11 +95,14 @@ class DecoderRunner:
             self.dg, self.dV0, self.dAmean = z((B, H)), z((B * K, H)), z((B, C))
 
     def check_sync(self):
-        """Raises if a grid barrier of the persistent recurrence kernels timed out in any launch so far (synchronises)."""
-        if bool(self.seq_sync[:, 1].any().item()):
+        """Raises if a grid barrier of the persistent recurrence kernels timed out in ANY launch since the last call (the
+        sticky word of each launch slot; reading it synchronises the device).  The flag is cleared when it is reported."""
+        if bool(self.seq_sync[:, 2].any().item()):
             from ._lib import CapmiError
-            raise CapmiError('capmi_lstm_seq: a grid barrier gave up waiting (sync words %s); the recurrence results are invalid'
-                             % self.seq_sync.cpu().tolist())
+            words = self.seq_sync.cpu().tolist()
+            self.seq_sync[:, 2].zero_()
+            raise CapmiError('capmi_lstm_seq: a grid barrier gave up waiting (sync words %s); the recurrence results of at least one '
+                             'step since the last check are invalid' % words)
 
     # ------------------------------------------------------------------ tiny helpers
     def _gemm(self, plan, x, rows, K, w, N, y, ldw=None, ldx=None, ldy=None, bias=None, addend=None, ld_add=0,

@@ -106,6 +106,7 @@ class NativeComm:
         # group: torch.distributed then never has to build a communicator of its own just to carry 128 bytes.
         store = dist.distributed_c10d._get_default_store()
         NativeComm._serial = getattr(NativeComm, '_serial', 0) + 1
+        NativeComm._made_on = getattr(NativeComm, '_made_on', set()) | {str(device)}
         key = 'capmi/comm/%d/' % NativeComm._serial
         if rank == 0:
             buf = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
@@ -121,24 +122,39 @@ class NativeComm:
         rc = L.capmi_comm_init(ctypes.byref(self.comm), world, rank, raw)
         if rc != 0:
             self.why = _lib.last_error()
-        else:       # self-test on the current stream
-            t = torch.ones(1024, dtype=torch.float32, device=device)
-            rc = L.capmi_allreduce_bucket(self.comm, t.data_ptr(), t.numel(), torch.cuda.current_stream(device).cuda_stream)
-            torch.cuda.synchronize(device)
-            if rc != 0:
-                self.why = _lib.last_error()
-            elif not bool((t == float(world)).all()):
-                rc, self.why = 1, 'self-test: sum of ones over %d ranks gave %r' % (world, float(t[0]))
+        # Every rank publishes the verdict of its capmi_comm_init BEFORE any collective runs on the new communicator, and the
+        # self-test all-reduce below is entered only when EVERY rank reports success: a rank whose set-up failed would
+        # otherwise leave the others waiting inside ncclAllReduce for ever (no time-out there).
+        store.set(key + 'init/%d' % rank, b'1' if rc == 0 else b'0')
+        if not all(bytes(store.get(key + 'init/%d' % r)) == b'1' for r in range(world)):
+            self.why = self.why or 'another rank failed in capmi_comm_init'
+            if rc == 0:
+                self.close()
+            return
+        # self-test on the current stream: a sum of ones must equal the world size on every rank
+        t = torch.ones(1024, dtype=torch.float32, device=device)
+        rc = L.capmi_allreduce_bucket(self.comm, t.data_ptr(), t.numel(), torch.cuda.current_stream(device).cuda_stream)
+        torch.cuda.synchronize(device)
+        if rc != 0:
+            self.why = _lib.last_error()
+        elif not bool((t == float(world)).all()):
+            rc, self.why = 1, 'self-test: sum of ones over %d ranks gave %r' % (world, float(t[0]))
         store.set(key + 'ok/%d' % rank, b'1' if rc == 0 else b'0')          # all ranks take the same path
         self.ok = all(bytes(store.get(key + 'ok/%d' % r)) == b'1' for r in range(world))
         if not self.ok and not self.why:
-            self.why = 'another rank failed to set up its communicator'
+            self.why = 'another rank failed the self-test of its communicator'
+
+    @staticmethod
+    def _serial_of(device):
+        """True when this process has already created a communicator on `device` (lane creation must come first)."""
+        return str(device) in getattr(NativeComm, '_made_on', set())
 
     def close(self):
         from . import _lib
         if self.comm:
             _lib.lib().capmi_comm_destroy(self.comm)
             self.comm = None
+        self.ok = False
 
 
 class OverlappedTrainer:
@@ -151,10 +167,18 @@ class OverlappedTrainer:
     that bucket's parameters (`CaptionEngine.optimizer_range`): the optimizer, too, runs under the remaining
     backward pass; the next forward waits for the side stream."""
 
-    def __init__(self, engine, bucket_bytes=32 << 20):
+    def __init__(self, engine, bucket_bytes=32 << 20, bucket_dtype=None):
         self.eng = engine
         self.bucket_bytes = bucket_bytes
         self.active = engine.world > 1 or (engine.pg is not None and os.environ.get('CAPMI_FORCE_DP', '0') not in ('', '0'))
+        # Payload type of the gradient exchange.  'bf16' (default of a bf16 engine; SURVEY.md section 8(e) budgets the exchange
+        # in bf16: 73 MB at BASELINE cfg 2 instead of 146): the bucket's f32 gradients are cast into a bf16 staging buffer by
+        # the bucket's producer lane, the ring sums in bf16, Adam widens them again (capmi_adam_g16).  'f32' (default of an f32
+        # engine, CAPMI_BUCKET_DTYPE=f32 anywhere): the reference's precision, ParallelExecutor all-reduces f32 gradients.
+        from ._lib import BF16
+        self.bucket_dtype = bucket_dtype or os.environ.get('CAPMI_BUCKET_DTYPE') or ('bf16' if engine.code == BF16 else 'f32')
+        if self.bucket_dtype not in ('f32', 'bf16'):
+            raise ValueError('bucket_dtype must be f32 or bf16, got %r' % (self.bucket_dtype,))
         # CAPMI_COMM_PRIORITY=-1 puts the bucket stream (all-reduce + the bucket's optimizer) above the backward kernels;
         # on one rank that costs 0.6 % (the optimizer then pre-empts the critical lane), untested on several GPUs
         prio = int(os.environ.get('CAPMI_COMM_PRIORITY', '0'))
@@ -170,6 +194,11 @@ class OverlappedTrainer:
             # single-rank fused step takes 9.27 on the same box)
             from ._lib import Plan
             with torch.cuda.device(engine.device):
+                if NativeComm._serial_of(engine.device) and 2 not in Plan._side.get(engine.device.index or 0, {}).get('streams', {}):
+                    # a communicator of this process already exists on the device and lane 2 does not: the lane would be created
+                    # BEHIND ncclCommInitRank -- the slow hardware-queue assignment described above.  Refuse it loudly.
+                    raise RuntimeError('dp.OverlappedTrainer: an RCCL communicator was created on %s before the plan lanes; build the '
+                                       'trainer (or call _lib.Plan._lane_streams({1, 2})) before any NativeComm' % engine.device)
                 Plan._lane_streams({1, 2})
             nc = NativeComm(engine.pg, dist.get_rank(engine.pg), dist.get_world_size(engine.pg), engine.device)
             if nc.ok and os.environ.get('CAPMI_NATIVE_COMM') == '2':       # timing experiment: communicator created, not used
@@ -223,6 +252,8 @@ class OverlappedTrainer:
         st = eng.store
         lrt = ctypes.c_float(0.0)
         total = st.trainable_size
+        g16 = eng.grad16() if self.bucket_dtype == 'bf16' else None
+        from ._lib import BF16
         step = Plan()
         step.extend(prog['fwd'])
         for i, (sub, (b, e), _) in enumerate(segs):
@@ -232,10 +263,19 @@ class OverlappedTrainer:
             if sub.has_lanes:                       # the segment's weight gradients (lane 1) are part of the bucket
                 step.record(('bucket', i, 1), 1)
                 step.wait(('bucket', i, 1), 2)
-            step.add('capmi_allreduce_bucket', self.native_comm.comm, st.grad.data_ptr() + b * 4, e - b, lane=2)
-            eng.plan_adam(step, b, e, lrt, 2, grad_scale=1.0 / eng.world)
+            if g16 is not None:                     # bf16 payload: cast -> all-reduce -> Adam reads the bf16 sum
+                step.add('capmi_cast', st.grad.data_ptr() + b * 4, g16.data_ptr() + b * 2, e - b, BF16, lane=2)
+                step.add('capmi_allreduce_bucket_bf16', self.native_comm.comm, g16.data_ptr() + b * 2, e - b, lane=2)
+            else:
+                step.add('capmi_allreduce_bucket', self.native_comm.comm, st.grad.data_ptr() + b * 4, e - b, lane=2)
+            eng.plan_adam(step, b, e, lrt, 2, grad_scale=1.0 / eng.world, g16=g16)
             eng.plan_shadow(step, b, st.size if e == total else e, 2)
         return step, lrt
+
+    def check_sync(self):
+        """CaptionEngine.check_sync for the engine this trainer drives: call it after a loop of train_step calls (the
+        step itself never synchronises)."""
+        self.eng.check_sync()
 
     def train_step(self, image, caption):
         eng = self.eng
@@ -272,10 +312,17 @@ class OverlappedTrainer:
             ev.record(cur)
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(grad[b:e], op=dist.ReduceOp.SUM, group=eng.pg)
+                g16 = None
+                if self.bucket_dtype == 'bf16':
+                    from . import _lib
+                    g16 = eng.grad16()
+                    _lib.call('capmi_cast', grad.data_ptr() + b * 4, g16.data_ptr() + b * 2, e - b, _lib.BF16, self.comm_stream.cuda_stream)
+                    dist.all_reduce(g16[b:e], op=dist.ReduceOp.SUM, group=eng.pg)
+                else:
+                    dist.all_reduce(grad[b:e], op=dist.ReduceOp.SUM, group=eng.pg)
                 # the bucket's parameters are final for this step: Adam + shadow refresh right behind its
                 # all-reduce, on the communication stream, under the rest of the backward pass
-                eng.optimizer_range(b, e, lr_t, self.comm_stream.cuda_stream, tail=(e == total))
+                eng.optimizer_range(b, e, lr_t, self.comm_stream.cuda_stream, tail=(e == total), g16=g16)
         cur.wait_stream(self.comm_stream)
         eng.shadows_dirty = False
         return prog['dec'].loss, lr

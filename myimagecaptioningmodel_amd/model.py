@@ -320,13 +320,23 @@ class CaptionEngine:
         self.shadows_dirty = True
         return lr
 
-    def optimizer_range(self, b, e, lr_t, stream, tail=False):
+    def grad16(self):
+        """bf16 staging copy of the trainable slice of the gradient buffer (same offsets): the payload of the data-parallel
+        all-reduce when the buckets travel in bf16 (dp.OverlappedTrainer, capmi_allreduce_bucket_bf16)."""
+        if getattr(self, '_grad16', None) is None:
+            self._grad16 = torch.zeros((self.store.trainable_size + 7) // 8 * 8, dtype=torch.bfloat16, device=self.device)
+        return self._grad16
+
+    def optimizer_range(self, b, e, lr_t, stream, tail=False, g16=None):
         """Adam + shadow refresh of flat range [b, e) on `stream` (a raw HIP stream): what optimizer_step +
         refresh_shadows do for the whole buffer, for one all-reduce bucket.  tail=True also refreshes the
-        shadows of everything behind e (non-trainable state)."""
+        shadows of everything behind e (non-trainable state).  g16: read the gradients from this bf16 buffer."""
         st, cfg = self.store, self.cfg
         clip = float(cfg['gradient_clip']) if cfg.get('gradient_clip') else 0.0
-        if e > b:
+        if e > b and g16 is not None:
+            _lib.call('capmi_adam_g16', st.flat.data_ptr() + b * 4, g16.data_ptr() + b * 2, st.adam_m.data_ptr() + b * 4,
+                      st.adam_v.data_ptr() + b * 4, e - b, lr_t, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, 1.0 / self.world, stream)
+        elif e > b:
             _lib.call('capmi_adam', st.flat.data_ptr() + b * 4, st.grad.data_ptr() + b * 4, st.adam_m.data_ptr() + b * 4,
                       st.adam_v.data_ptr() + b * 4, e - b, lr_t, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, 1.0 / self.world, stream)
         hi = st.size if tail else e
@@ -343,11 +353,15 @@ class CaptionEngine:
         if self.world > 1:
             torch.distributed.all_reduce(self.store.grad[:self.store.trainable_size], group=self.pg)
 
-    def plan_adam(self, plan, b, e, lrt, lane, grad_scale=1.0):
-        """Adam over flat range [b, e) as a plan entry; lrt: a ctypes.c_float re-read before every run."""
+    def plan_adam(self, plan, b, e, lrt, lane, grad_scale=1.0, g16=None):
+        """Adam over flat range [b, e) as a plan entry; lrt: a ctypes.c_float re-read before every run; g16: gradients
+        from this bf16 buffer (same offsets) instead of the f32 gradient buffer."""
         st, cfg = self.store, self.cfg
         clip = float(cfg['gradient_clip']) if cfg.get('gradient_clip') else 0.0
-        if e > b:
+        if e > b and g16 is not None:
+            plan.add('capmi_adam_g16', st.flat.data_ptr() + b * 4, g16.data_ptr() + b * 2, st.adam_m.data_ptr() + b * 4,
+                     st.adam_v.data_ptr() + b * 4, e - b, lrt, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, grad_scale, lane=lane)
+        elif e > b:
             plan.add('capmi_adam', st.flat.data_ptr() + b * 4, st.grad.data_ptr() + b * 4, st.adam_m.data_ptr() + b * 4,
                      st.adam_v.data_ptr() + b * 4, e - b, lrt, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, grad_scale, lane=lane)
 
@@ -458,8 +472,10 @@ class CaptionEngine:
         return prog['out']
 
     def check_sync(self):
-        """Raises CapmiError if a grid barrier inside a persistent kernel gave up waiting in any step so far (reads 4 bytes
-        per launch slot back: synchronises the device)."""
+        """Raises CapmiError if a grid barrier inside a persistent kernel gave up waiting in any step since the last call
+        (the sticky word of every launch slot is read back: synchronises the device).  train_loop.train and Executor.run
+        call it every step; callers that drive train_step / OverlappedTrainer.train_step themselves (bench.py, tools/) call
+        it once after their timed loop -- a timed-out barrier means the losses, weights and rates of that loop are invalid."""
         for prog in self._train.values():
             prog['dec'].check_sync()
 

@@ -33,34 +33,74 @@ def load_model(engine, conf, checkpoint_path, log_path, pretrained_encoder_path=
             ckpt.load_vars_existing(engine, pretrained_encoder_path)
 
 
+def _rank_world(engine):
+    pg = getattr(engine, 'pg', None)
+    if pg is None:
+        return 0, 1, None
+    import torch.distributed as dist
+    return dist.get_rank(pg), dist.get_world_size(pg), dist
+
+
 def train(engine, batches_per_epoch, max_epoch, checkpoint_path, log_path, log_every_n_step=150,
-          pretrained_encoder_path=None, checkpoint_backup_every_n_epoch=0, export_params=False):
+          pretrained_encoder_path=None, checkpoint_backup_every_n_epoch=0, export_params=False,
+          trainer=None, eval_score=None, save_best_bleu_checkpoint=True):
     """batches_per_epoch: callable epoch -> iterable of {'image': ..., 'caption': ...} feeds
     (the reader contract of reader.py:45-47,65).  Resumes from `<log_path>/config` like the reference: the epoch is
     written at the START of each epoch (train.py:134), so a crash inside epoch N restarts epoch N from the
-    checkpoint written at the end of epoch N-1 (and a crash inside epoch 1 starts from scratch)."""
-    conf = ckpt.load_resume_state(log_path, engine.cfg['encoder_trainable'])
-    load_model(engine, conf, checkpoint_path, log_path, pretrained_encoder_path)
+    checkpoint written at the end of epoch N-1 (and a crash inside epoch 1 starts from scratch).
+
+    trainer: a dp.OverlappedTrainer around `engine` -- the data-parallel step (train.py:121-124: the SAME
+    ParallelExecutor runs the loop, :139); every rank runs this function on its own shard of each batch, rank 0 alone
+    writes the checkpoint directory, the resume JSON and the log (one process saves in the reference: :172), every rank
+    loads them, and a barrier separates the write from the next read.
+    eval_score: callable epoch -> score of the dev evaluation (the reference computes BLEU with nltk, evaluate.py:45-74,
+    out of scope here: the CALLER supplies the number).  When it beats `best_bleu` of the resume JSON the persistables are
+    also written to `<checkpoint_path>/checkpoint_best_bleu` and the JSON is updated (train.py:85-91, logger.py best_bleu)."""
+    rank, world, dist = _rank_world(engine)
+    lead = rank == 0
+
+    def barrier():
+        if dist is not None and world > 1:
+            dist.barrier(group=engine.pg)
+    if lead:
+        conf = ckpt.load_resume_state(log_path, engine.cfg['encoder_trainable'])       # creates the JSON on first use
+    barrier()
+    if not lead:
+        conf = ckpt.load_resume_state(log_path, engine.cfg['encoder_trainable'])
+    if lead:
+        load_model(engine, conf, checkpoint_path, log_path, pretrained_encoder_path)
+    barrier()
+    if not lead:        # reads only: the train_encoder flip (if any) was recorded by rank 0 above
+        load_model(engine, dict(conf, train_encoder=bool(engine.cfg['encoder_trainable'])), checkpoint_path, log_path, pretrained_encoder_path)
+    step_fn = trainer.train_step if trainer is not None else engine.train_step
     for epoch in range(conf['epoch'], max_epoch + 1):
         conf['epoch'] = epoch                                   # written at the START of the epoch (train.py:134)
-        ckpt.save_resume_state(log_path, conf)
-        log(log_path, 'Epoch {}'.format(epoch))
+        if lead:
+            ckpt.save_resume_state(log_path, conf)
+            log(log_path, 'Epoch {}'.format(epoch))
         epoch_loss, step = 0.0, -1
         for step, data in enumerate(batches_per_epoch(epoch)):
-            loss, lr = engine.train_step(data['image'], data['caption'])
+            loss, lr = step_fn(data['image'], data['caption'])
             step_loss = loss.detach().cpu().numpy()
             engine.check_sync()
             if np.isnan(step_loss).any():                       # train.py:140-141
                 raise AssertionError('Epoch:{} Step:{} Loss为Nan'.format(epoch, step + 1))
             epoch_loss += float(step_loss[0])
-            if (step + 1) % log_every_n_step == 0:
+            if lead and (step + 1) % log_every_n_step == 0:
                 log(log_path, ' ' * 4 + 'Step {} Mean loss: {:6f} Step loss: {:6f}, lr: {}'.format(
                     step + 1, epoch_loss / (step + 1), float(step_loss[0]), str(np.float32(lr))))
-        log(log_path, 'Epoch loss: {:7f}'.format(epoch_loss / max(1, step + 1)))
-        ckpt.save_persistables(engine, os.path.join(checkpoint_path, 'checkpoint'))   # train.py:172 -> :73
-        n = checkpoint_backup_every_n_epoch
-        if n and epoch % n == 0:                                                      # :74-76
-            ckpt.save_persistables(engine, os.path.join(checkpoint_path, 'checkpoint{}'.format(epoch)))
-        if export_params:                                                             # :78-79
-            ckpt.save_params(engine, os.path.join(checkpoint_path, 'params'))
+        score = eval_score(epoch) if eval_score is not None else None                 # train.py:151-169 (dev BLEU)
+        if lead:
+            log(log_path, 'Epoch loss: {:7f}'.format(epoch_loss / max(1, step + 1)))
+            ckpt.save_persistables(engine, os.path.join(checkpoint_path, 'checkpoint'))   # train.py:172 -> :73
+            n = checkpoint_backup_every_n_epoch
+            if n and epoch % n == 0:                                                      # :74-76
+                ckpt.save_persistables(engine, os.path.join(checkpoint_path, 'checkpoint{}'.format(epoch)))
+            if export_params:                                                             # :78-79
+                ckpt.save_params(engine, os.path.join(checkpoint_path, 'params'))
+            if save_best_bleu_checkpoint and score is not None and score > conf.get('best_bleu', 0):   # :85-88
+                conf['best_bleu'] = float(score)
+                ckpt.save_resume_state(log_path, conf)                                    # logger.py: the setter saves the JSON
+                ckpt.save_persistables(engine, os.path.join(checkpoint_path, 'checkpoint_best_bleu'))
+        barrier()                                                                         # nobody runs ahead of the files
     return conf

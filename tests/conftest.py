@@ -32,3 +32,13 @@ def tiny_cfg():
     from oracle.model import default_cfg
     return default_cfg(encoder='mobilenetv2', image_size=64, hidden=32, embed=16, vocab=50,
                        sentence_length=6, infer_max_length=6)
+
+
+@pytest.fixture
+def deterministic():
+    """capmi_set_deterministic(1) for the test (include/capmi.h): fixed-order reductions in place of every f32 atomic
+    accumulation, so that launch-schedule variants of one computation can be compared with array_equal."""
+    from myimagecaptioningmodel_amd import _lib
+    prev = _lib.set_deterministic(True)
+    yield
+    _lib.set_deterministic(prev)

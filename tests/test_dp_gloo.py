@@ -55,10 +55,17 @@ def _worker(rank, world, port, out):
     summed = {n: flat[offs[i]:offs[i + 1]].numpy().reshape(grads[n].shape) for i, n in enumerate(names)}
     p_new, _, _ = ops.adam_update(params['lstm_w'], summed['lstm_w'] / world, np.zeros_like(params['lstm_w']),
                                   np.zeros_like(params['lstm_w']), 1e-3, 1)
+    # bf16 payload (dp.OverlappedTrainer bucket_dtype='bf16'): each rank casts its f32 gradients to bf16, the
+    # buckets are summed in bf16, Adam widens the sum again
+    own16 = torch.from_numpy(np.concatenate([grads[n].ravel() for n in names])).float().bfloat16()
+    sum16 = own16.clone()
+    dp.allreduce_flat(sum16, buckets, group=pg)
+    i = names.index('lstm_w')
     if rank == 0:
-        out.put(dict(p_new=p_new, summed_lstm=summed['lstm_w'], own=grads['lstm_w']))
+        out.put(dict(p_new=p_new, summed_lstm=summed['lstm_w'], own=grads['lstm_w'], own16=own16[offs[i]:offs[i + 1]].float().numpy(),
+                     sum16=sum16[offs[i]:offs[i + 1]].float().numpy()))
     else:
-        out.put(dict(own=grads['lstm_w']))
+        out.put(dict(own=grads['lstm_w'], own16=own16[offs[i]:offs[i + 1]].float().numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -86,6 +93,13 @@ def test_two_rank_gloo_allreduce_matches_parallel_executor_semantics():
     mean_g = (r0['own'] + r1['own']) / 2
     want, _, _ = ops.adam_update(params['lstm_w'], mean_g, np.zeros_like(mean_g), np.zeros_like(mean_g), 1e-3, 1)
     np.testing.assert_allclose(r0['p_new'], want, rtol=1e-12, atol=1e-15)
+    # bf16 payload: the bucketed bf16 all-reduce is the bf16 sum of the two ranks' bf16 casts (one rounding of the f32 sum of
+    # two bf16 values), i.e. within 2^-8 relative of the f32 sum of the casts and within ~2^-7 of the exact sum
+    a, b = torch.from_numpy(r0['own16']).bfloat16(), torch.from_numpy(r1['own16']).bfloat16()
+    np.testing.assert_array_equal(r0['sum16'], (a + b).float().numpy())
+    exact = (r0['own'] + r1['own']).ravel()
+    err = np.abs(r0['sum16'].ravel() - exact)
+    assert (err <= 2.0 ** -7 * (np.abs(r0['own']).ravel() + np.abs(r1['own']).ravel()) + 1e-30).all()
 
 
 def test_grad_buckets_cut_only_at_segment_boundaries():

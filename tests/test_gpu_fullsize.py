@@ -92,21 +92,24 @@ def test_output_bias_gradient_sums_to_zero_and_padding_is_inert(full):
     assert np.isfinite(l_short) and l_short > 0
 
 
-def test_two_lane_schedule_equals_the_single_stream_order(full, monkeypatch):
+def test_two_lane_schedule_equals_the_single_stream_order(full, monkeypatch, deterministic):
     """The recorded launch order is a valid single-stream order: the same step with
-    CAPMI_LANES=0 gives the same loss and gradients up to atomic summation order."""
+    CAPMI_LANES=0 gives the same loss and the same gradients BIT FOR BIT at full size (deterministic mode: every
+    accumulation has a fixed order, so nothing may depend on how the lanes interleave -- a missed event wait or a
+    buffer reused too early shows up here as a differing element)."""
     from myimagecaptioningmodel_amd.model import CaptionEngine
     cfg, eng, image, cap, params = full
     l0 = _loss(eng, image, cap)
     g0 = eng.store.grad[:eng.store.trainable_size].clone()
+    l0b = _loss(eng, image, cap)                 # and the two-lane step reproduces itself
+    assert l0b == l0 and torch.equal(eng.store.grad[:eng.store.trainable_size], g0)
     monkeypatch.setenv('CAPMI_LANES', '0')
     eng1 = CaptionEngine(cfg, device='cuda:0', use_graph=False)
     eng1.load_reference_params(params)
     l1 = _loss(eng1, image, cap)
     g1 = eng1.store.grad[:eng1.store.trainable_size]
-    assert abs(l1 - l0) <= 1e-4, (l0, l1)
-    rel = float((g1 - g0).norm() / g0.norm())
-    assert rel < 1e-3, rel
+    assert l1 == l0, (l0, l1)
+    assert torch.equal(g1, g0), float((g1 - g0).abs().max())
 
 
 def test_inference_decode_is_idempotent_and_beam_one_is_greedy(full):
@@ -147,6 +150,45 @@ def test_beam_five_at_full_size_mostly_scores_at_least_the_greedy_caption(full):
     tol = 2e-3 * np.abs(s1) + 2e-2
     assert np.mean(s5 >= s1 - tol) >= 0.8, np.sort(s5 - s1)[:8]
     assert np.median(s5 - s1) >= -float(np.median(tol))
+
+
+def test_configs4_beam_five_at_batch_128():
+    """BASELINE configs[4] at its STATED size: the infer.py path (infer.py:26-36; exported model = `is_test` batch norm) on
+    ResNet-50 + 512-d decoder, 224x224, batch 128, beam 5, Ti = 20.  No oracle at this size, so: ids are integral
+    vocabulary indices as float32 (quirk Q2); the decode is idempotent (hipGraph replay and eager plan agree bit for bit);
+    a beam of one through the beam-search plan is the greedy loop bit for bit (:119-123) with the greedy caption's
+    log-probability; the batch is separable -- with running statistics every image is independent of its neighbours, so
+    images 0..63 decoded inside the batch of 128 score what they score in a batch of 64 (up to bf16 GEMM-tile noise) and
+    mostly yield the same captions; and the best of five scores at least the greedy caption on most images."""
+    from myimagecaptioningmodel_amd import default_cfg
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+    B4 = 128
+    cfg = default_cfg(batch_size=B4, sample_count=0, **bench.WORKLOAD)
+    image, _ = bench.synthetic_batch(B4, cfg, 1234)
+    eng = CaptionEngine(cfg, device='cuda:0', use_graph=True)
+    five = eng.decode(image, beam=5, is_test=True).cpu().numpy().copy()          # call 1: eager warm-up + capture
+    s5 = eng.decode_scores(B4, 5, is_test=True).cpu().numpy().copy()
+    again = eng.decode(image, beam=5, is_test=True).cpu().numpy()                # call 2: hipGraph replay
+    np.testing.assert_array_equal(five, again)
+    np.testing.assert_array_equal(s5, eng.decode_scores(B4, 5, is_test=True).cpu().numpy())
+    assert five.shape == (B4, cfg['infer_max_length']) and five.dtype == np.float32
+    assert ((five >= 0) & (five < cfg['vocab'])).all() and (five == np.round(five)).all()
+    greedy = eng.decode(image, is_test=True).cpu().numpy().copy()
+    one = eng.decode(image, beam=1, is_test=True, scored=True).cpu().numpy()
+    s1 = eng.decode_scores(B4, 1, is_test=True).cpu().numpy().copy()
+    np.testing.assert_array_equal(greedy, one)
+    assert np.isfinite(s1).all() and np.isfinite(s5).all() and (s5 <= 0).all()
+    tol = 2e-3 * np.abs(s1) + 2e-2
+    assert np.mean(s5 >= s1 - tol) >= 0.8, np.sort(s5 - s1)[:8]
+    # separability: the first 64 images alone
+    half = eng.decode(image[:64], beam=5, is_test=True).cpu().numpy().copy()
+    sh = eng.decode_scores(64, 5, is_test=True).cpu().numpy().copy()
+    same = np.mean((half == five[:64]).all(axis=1))
+    print('configs[4]: captions equal between the batch of 128 and its first half alone: %.0f %%; max |score gap| %.3g' % (100 * same, np.abs(sh - s5[:64]).max()))
+    assert np.median(np.abs(sh - s5[:64])) <= float(np.median(tol)) and same >= 0.5
+    eng.check_sync()
+    del eng
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('workload', list(WORKLOADS))

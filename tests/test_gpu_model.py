@@ -10,6 +10,8 @@ Tolerances (stated per BASELINE.json's north_star: loss within 1e-3, argmax ids 
   of the model, which is what bounds a per-tensor claim, not the kernels); greedy ids bit-exact;
   bf16 engine: |loss| <= 5e-2, gradient direction cos >= 0.97.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -102,6 +104,15 @@ def test_f32_train_step_matches_oracle(encoder, attention, S):
                 ratio = max(ratio, (err / max(noise, 2e-3 * nrm, floor), name))
         print('step %d worst relative-L2 gradient error %.2e (%s); worst error / max(f32 noise of that tensor, 2e-3) = %.2f (%s)' % (
             step, worst[0], worst[1], ratio[0], ratio[1]))
+        # the bound on the printed figure: no tensor further from the f64 oracle than 20 x what the f32 evaluation of the
+        # same graph in NumPy is (observed 0.6 .. 14 -- the kernels sit at the f32 noise of this input, not above it);
+        # recorded next to the test so that a drift shows up as a number, not only as a pass
+        assert ratio[0] <= 20.0, (step, ratio)
+        rec = os.environ.get('CAPMI_TEST_RECORD')
+        if rec:
+            with open(rec, 'a') as fh:
+                fh.write('test_f32_train_step_matches_oracle step %d: worst error-to-noise ratio %.3f (%s), worst relative L2 %.3e (%s)\n'
+                         % (step, ratio[0], ratio[1], worst[0], worst[1]))
         if attention == 'singleton':      # quirk Q1: exactly zero gradient, parameters never move
             for n in ('fc_3', 'fc_8', 'fc_9', 'fc_10'):
                 assert np.all(grads_e[n + '.w_0'] == 0) and np.all(grads_e[n + '.b_0'] == 0)

@@ -35,7 +35,7 @@ def test_library_exports_every_header_symbol_with_matching_signature():
         if name.startswith('capmi_plan_'):        # bound by hand in _lib.lib() (struct pointer / string results); used below
             assert getattr(L, name).argtypes is not None or name == 'capmi_plan_entry_count'
             continue
-        sig = _lib.SIGNATURES.get(name) or _lib.QUERIES.get(name) or _lib.SYNC.get(name) or _lib.COMM.get(name)
+        sig = next((d[name] for d in (_lib.SIGNATURES, _lib.QUERIES, _lib.SYNC, _lib.COMM) if name in d), None)
         assert sig is not None, 'no ctypes signature for %s' % name
         arglist = [a.strip() for a in args.split(',') if a.strip() and a.strip() != 'void']
         assert len(sig) == len(arglist), (name, len(sig), len(arglist))

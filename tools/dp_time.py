@@ -33,5 +33,6 @@ for _ in range(n):
     tr.train_step(image, cap)
 torch.cuda.synchronize()
 print('back to back: %.2f ms/step' % ((time.perf_counter() - t0) / n * 1e3))
+tr.check_sync()         # a timed-out grid barrier anywhere above voids the numbers
 import torch.distributed as dist
 dist.destroy_process_group()
