@@ -94,6 +94,20 @@ int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi_conv_geom*
                    const void* ysaved, int ld_saved, float* stats,
                    int act, int dact, int out_f32, int dtype, void* stream);
 
+/* Convolution on the RAW output of the producing convolution, with that producer's batch norm + activation applied in
+ * the A-operand path:  y = conv( act(in_coef_a * (x_raw - in_mean) + in_offset) )  -- the formula and rounding points of
+ * capmi_bn_apply, so the result equals capmi_bn_apply followed by capmi_igemm_nt bit for bit, but the normalised tensor
+ * is never written to or read from memory for this consumer.  Replaces the `conv2d(batch_norm(conv2d(..)))` links inside
+ * a unit chain (IC/model/MobileNetV2.py:88-121 conv_bn_layer, :128-181 / the ResNet bottleneck: conv1 -> conv2 -> conv3).
+ * bf16 only; two kernel families carry it -- the halo-staged 3x3 / stride 1 / pad 1 kernel (rows of <= 56 pixels) and the
+ * LDS-DMA kernel on 1x1 convolutions -- with Cin <= 512, Cin % 32 == 0, ldx == Cin: ask capmi_igemm_nt_bnact_supported
+ * (1 / 2 = which family, 0 = materialise the tensor and call capmi_igemm_nt).  in_act: CAPMI_ACT_RELU or _RELU6.
+ * stats as capmi_igemm_nt (same part height).  The vectors are f32 [Cin], 16-byte aligned. */
+int capmi_igemm_nt_bnact_supported(const capmi_conv_geom* g, int N, int dtype);
+int capmi_igemm_nt_bnact(const void* x_raw, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                         const float* in_mean, const float* in_coef_a, const float* in_offset, int in_act,
+                         float* stats, int dtype, void* stream);
+
 /* Several independent capmi_igemm_nt products with disjoint outputs (the output-parity classes of a
  * strided convolution's data gradient: small GEMMs that under-fill the chip one at a time), issued
  * together.  Semantics = the calls one after another (bias, statistics, act off, output in `dtype`);

@@ -40,6 +40,7 @@ _g = ctypes.POINTER(ConvGeom)
 SIGNATURES = {
     'capmi_igemm_nt': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _i, _p, _i, _p, _i, _i, _i, _i, _p],
     'capmi_igemm_nt_bn': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _p, _i, _i, _i, _p],
+    'capmi_igemm_nt_bnact': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     'capmi_igemm_nt_bnred': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'capmi_igemm_nt_group': [ctypes.POINTER(NtCall), _i, _i, _p],
     'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
@@ -106,6 +107,7 @@ class CapmiError(RuntimeError):
 QUERIES = {
     'capmi_igemm_nt_stats_part_rows': [_i, _i, _i, _i],
     'capmi_igemm_nt_bnred_part_rows': [_g, _i, _i],
+    'capmi_igemm_nt_bnact_supported': [_g, _i, _i],
     'capmi_bn_stats_part_rows': [_i, _i, _i],
     'capmi_lstm_step_supported': [_i, _i, _i],
     'capmi_lstm_seq_supported': [_i, _i, _i, _i],

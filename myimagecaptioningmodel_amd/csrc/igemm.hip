@@ -33,6 +33,12 @@ struct IGemmArgs {
     const float* bias;
     const float* bn_mean;            // inference batch norm in the epilogue (capmi_igemm_nt_bn): acc -> bn_a * (acc - bn_mean) + bias
     const float* bn_a;
+    // batch norm + activation of the INPUT operand, applied in the A-operand path (capmi_igemm_nt_bnact): x holds the RAW
+    // output of the producing convolution, the kernel multiplies act(in_a * (x - in_mean) + in_off) -- bn_apply's formula
+    const float* in_mean;
+    const float* in_a;
+    const float* in_off;
+    int in_act;
     const void* addend;
     const void* ysaved;
     float* stats;
@@ -284,6 +290,35 @@ template <int TN> __device__ __forceinline__ void dact_run(float (&v)[TN], const
             for (int e = 0; e < TN; ++e) v[e] *= y[e] * (1.f - y[e]);
             break;
         default: break;
+    }
+}
+
+// ------------------------------------------------------------------ batch norm + activation on 8 bf16 operand values
+// The formula and rounding points of bn_apply_kernel (bn_ops.hip): act(a * (x - mean) + offset) in f32, rounded to bf16
+// once -- a consumer that applies it to the RAW conv output multiplies the bits bn_apply would have stored.
+// ca / mu / of: this lane's 8 consecutive channels.  fmaxf(NaN, 0) = 0: a NaN operand (the padding page of the fused
+// weight gradient) comes out as an exact zero.
+constexpr int INBN_KMAX = 512;          // channels of the input tensor the coefficient table in LDS holds
+__device__ __forceinline__ bf16x8 bn_act8(bf16x8 v, const f32x4& ca0, const f32x4& ca1, const f32x4& mu0, const f32x4& mu1,
+                                          const f32x4& of0, const f32x4& of1, int act) {
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a = e < 4 ? ca0[e & 3] : ca1[e & 3], m = e < 4 ? mu0[e & 3] : mu1[e & 3], b = e < 4 ? of0[e & 3] : of1[e & 3];
+        float f = a * ((float)v[e] - m) + b;
+        f = fmaxf(f, 0.f);
+        if (act == CAPMI_ACT_RELU6) f = fminf(f, 6.f);
+        o[e] = (bf16)f;
+    }
+    return o;
+}
+// the coefficient table [3][INBN_KMAX] f32 (a | mean | offset) of an input tensor with C channels: plain loads + LDS stores
+// by the first C / 4 threads; the caller orders them before the first read (lgkmcnt(0) + a workgroup barrier)
+__device__ __forceinline__ void inbn_load_table(float* tab, const IGemmArgs& a, int C, int tid) {
+    if (tid * 4 < C) {
+        *reinterpret_cast<f32x4*>(tab + tid * 4) = *reinterpret_cast<const f32x4*>(a.in_a + tid * 4);
+        *reinterpret_cast<f32x4*>(tab + INBN_KMAX + tid * 4) = *reinterpret_cast<const f32x4*>(a.in_mean + tid * 4);
+        *reinterpret_cast<f32x4*>(tab + 2 * INBN_KMAX + tid * 4) = *reinterpret_cast<const f32x4*>(a.in_off + tid * 4);
     }
 }
 
@@ -681,9 +716,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // KG = 2 / 4: 8 / 16 waves in KG k-groups -- group g takes the k-steps s with s % KG == g (its own part of every ring slot)
 // and the groups' accumulators meet in LDS before the epilogue.  Same tile, same bytes, twice the waves: for
 // deep-K layers whose grid is below ~2 workgroups per CU the loop is bound by per-wave latency, not by MFMA.
-template <int BM, int BN, int NST, bool RED, int LIN, int KG = 1>
+// INBN (LIN = 1 only: a 1x1 convolution, no padding): batch norm + ReLU of the input tensor applied to the A fragments
+// after the LDS read -- x is the producing convolution's RAW output, its normalised / activated form is never stored
+// (MobileNetV2.py:88-121: conv -> batch_norm -> relu is ONE unit of the reference graph; the unit boundary moves from
+// the producer's output to the consumer's operand).  With 4x1 waves every A row belongs to one wave, so the transform runs
+// once per staged element; per-channel coefficients come from a table in LDS.
+template <int BM, int BN, int NST, bool RED, int LIN, int KG = 1, bool INBN = false>
 __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int nblocks) {
     typedef bf16 T;
+    static_assert(!INBN || (LIN == 1 && KG == 1 && !RED), "operand-path batch norm: 1x1 convolutions on the plain kernel");
     constexpr int BK = 32, WMW = 4;
     constexpr int TM = BM / 64, TN = BN / 16;           // 4x1 waves: BM/4 rows x BN columns each
     constexpr int AOPB = BM * BK * 2, BOPB = BN * BK * 2;   // bytes of the A / B operand tiles
@@ -691,6 +732,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     constexpr int ACNT = BM / 64, BCNT = BN / 64;       // DMA instructions per thread per stage
     constexpr int NGL = ACNT + BCNT;
     __shared__ __attribute__((aligned(1024))) char smem[NST * KG * STB < 4096 ? 4096 : NST * KG * STB];
+    __shared__ __attribute__((aligned(16))) float inbn_tab[INBN ? 3 * INBN_KMAX : 4];
 
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ W = (const T*)a.w;
@@ -788,6 +830,10 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p)
         if (!(CAPMI_NT_ABL & 4)) issue_stage(p);
+    if constexpr (INBN) {       // behind the prologue's DMA issues: the table's own load latency hides under them; published by the
+        inbn_load_table(inbn_tab, a, a.K, tid);                  // first k-step's barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     int slot = 0;                                            // ring slot of stage kt
     for (int kt = 0; kt < nkt; ++kt) {
         // this thread's part of stage kt has landed (the (NST-2)*NGL younger DMAs may still be in flight)
@@ -803,10 +849,24 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         for (int i = 0; i < TM; ++i) af[i].load(reinterpret_cast<const T*>(st + aoff[i]));
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j].load(reinterpret_cast<const T*>(st + boff[j]));
+        f32x4 cf[INBN ? 6 : 1];
+        if constexpr (INBN) {   // this lane's 8 channels of the k-step: kt * 32 + 8 fg .. + 7 (16-lane groups read the same words: broadcast)
+            const float* t = inbn_tab + kt * BK + fg * 8;
+            cf[0] = *reinterpret_cast<const f32x4*>(t);
+            cf[1] = *reinterpret_cast<const f32x4*>(t + 4);
+            cf[2] = *reinterpret_cast<const f32x4*>(t + INBN_KMAX);
+            cf[3] = *reinterpret_cast<const f32x4*>(t + INBN_KMAX + 4);
+            cf[4] = *reinterpret_cast<const f32x4*>(t + 2 * INBN_KMAX);
+            cf[5] = *reinterpret_cast<const f32x4*>(t + 2 * INBN_KMAX + 4);
+        }
         // every fragment read is issued before the first MFMA: one exposed LDS latency per k-step instead of one
         // per pair of MFMAs (the scheduler otherwise recycles two fragment registers; grids below ~2 waves per
         // SIMD have nobody to hide that behind)
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (INBN) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i].v = bn_act8(af[i].v, cf[0], cf[1], cf[2], cf[3], cf[4], cf[5], a.in_act);
+        }
         if (CAPMI_NT_ABL & 1) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) acc[i][0][0] += (float)af[i].v[0];
@@ -849,6 +909,12 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
     nt_glds_body<BM, BN, NST, RED, LIN>(a, blockIdx.x, gridDim.x);
 }
 
+// 1x1 convolution whose input is the producer's RAW output: batch norm + ReLU in the A-operand path (nt_glds_body, INBN)
+template <int BM, int BN>
+__global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_glds_inbn_kernel(IGemmArgs a) {
+    nt_glds_body<BM, BN, 3, false, 1, 1, true>(a, blockIdx.x, gridDim.x);
+}
+
 template <int BM, int BN, int NST, int LIN, int KG>
 __global__ __launch_bounds__(256 * KG, (KG == 2 && BM == 64) ? 2 : 1) void igemm_nt_glds_kg_kernel(IGemmArgs a) {
     nt_glds_body<BM, BN, NST, false, LIN, KG>(a, blockIdx.x, gridDim.x);
@@ -867,7 +933,12 @@ __global__ __launch_bounds__(256 * KG, (KG == 2 && BM == 64) ? 2 : 1) void igemm
 //   pipeline: filter tiles in a 3-slot ring (as above), halo tiles double-buffered, the next chunk's halo issued at tap 0;
 //   the DMA returns in issue order, so `vmcnt` only has to leave the issues of LATER steps outstanding (see the loop).
 // Same weight-row permutation, accumulator layout and epilogue as the kernels above.
-template <int BM, int BN>
+// INBN: the input is the producing convolution's RAW output; batch norm + ReLU (bn_apply's formula, bn_act8) is applied to
+// the halo tile IN LDS, once per staged element: every thread transforms the 16-byte pieces its own DMA wrote (it knows
+// they have landed from its own vmcnt; nobody else touches them) -- chunk 0's in the prologue, chunk c + 1's spread over
+// taps 2.. of chunk c, under that chunk's MFMAs, into the buffer nobody reads yet.  Padding / out-of-image rows are zeroed per
+// lane AFTER the fragment read (vmask), so what the transform makes of their zero-page bytes never reaches an MFMA.
+template <int BM, int BN, bool INBN = false>
 __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(IGemmArgs a) {
     typedef bf16 T;
     constexpr int BK = 32, WMW = 4;
@@ -877,6 +948,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
     constexpr int ACNT = HR / 64, BCNT = BN / 64;               // DMA instructions per thread: halo tile / filter tile
     constexpr int AHB = HR * 64, BOPB = BN * BK * 2, NSTB = 3;
     __shared__ __attribute__((aligned(1024))) char smem[2 * AHB + NSTB * BOPB];
+    __shared__ __attribute__((aligned(16))) float inbn_tab[INBN ? 3 * INBN_KMAX : 4];
     char* const bring = smem + 2 * AHB;
 
     const T* __restrict__ X = (const T*)a.x;
@@ -960,10 +1032,38 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int nch = Cin / BK;
+    // operand-path batch norm: piece i of this thread (LDS row 64 i + 16 wave + (lane >> 2), position lane & 3) holds the
+    // global chunk (lane & 3) ^ G((lane >> 4) & 3) of its row -- the same for every i -- i.e. channels 32 cc + 8 gch .. + 7
+    const int gch = (lane & 3) ^ lds_swz4(lane >> 4);
+    auto transform_piece = [&](int buf, int i, const f32x4 (&cf)[6]) {
+        bf16x8* ptr = reinterpret_cast<bf16x8*>(smem + buf * AHB + wave * 1024 + i * 4096 + lane * 16);
+        *ptr = bn_act8(*ptr, cf[0], cf[1], cf[2], cf[3], cf[4], cf[5], a.in_act);
+    };
+    auto load_coef = [&](int cc, f32x4 (&cf)[6]) {
+        const float* t = inbn_tab + cc * BK + gch * 8;
+        cf[0] = *reinterpret_cast<const f32x4*>(t);
+        cf[1] = *reinterpret_cast<const f32x4*>(t + 4);
+        cf[2] = *reinterpret_cast<const f32x4*>(t + INBN_KMAX);
+        cf[3] = *reinterpret_cast<const f32x4*>(t + INBN_KMAX + 4);
+        cf[4] = *reinterpret_cast<const f32x4*>(t + 2 * INBN_KMAX);
+        cf[5] = *reinterpret_cast<const f32x4*>(t + 2 * INBN_KMAX + 4);
+    };
+    if constexpr (INBN) {
+        inbn_load_table(inbn_tab, a, Cin, tid);
+        __syncthreads();
+    }
     // prologue: halo of chunk 0, filter tiles of steps 0 and 1 (taps 0 and 1 of chunk 0)
     issue_A(0, 0, true);
     issue_B(0, 0, true);
     issue_B(1, Cin, true);
+    f32x4 cfn[INBN ? 6 : 1];                                    // coefficients of the chunk being transformed
+    if constexpr (INBN) {
+        wait_vmcnt<0>();                                        // this thread's pieces of chunk 0 have landed
+        load_coef(0, cfn);
+#pragma unroll
+        for (int i = 0; i < ACNT; ++i) transform_piece(0, i, cfn);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // ... and are rewritten before the first step's barrier
+    }
     int slot = 0;                                               // ring slot of the current step's filter tile
     for (int cc = 0; cc < nch; ++cc) {
         const char* abuf = smem + (cc & 1) * AHB;
@@ -1009,6 +1109,15 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma16(acc[i][j], af[i], bf[j]);
+            if constexpr (INBN) {
+                // next chunk's halo tile (issued at tap 0 of this chunk; from tap 2 on this thread's vmcnt wait has covered it):
+                // one piece per tap, under this step's MFMAs, in the buffer that is read from the next chunk's tap 0 on
+                if (tap >= 2 && tap < 2 + ACNT && cc + 1 < nch) {
+                    if (tap == 2) load_coef(cc + 1, cfn);
+                    transform_piece((cc + 1) & 1, tap - 2, cfn);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the rewritten piece is in LDS before this wave's next barrier
+                }
+            }
             // The tap loop is unrolled, so without this the scheduler sinks the MFMAs of a step -- and with them the
             // lgkmcnt wait for its fragment reads -- below the NEXT step's barrier and DMA issue: the refill of the slot
             // those reads come from was then in flight while the reads were not yet known to have returned (WAR on LDS;
@@ -1808,6 +1917,7 @@ static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const
     CAPMI_CHECK(g->os <= 1 || (!stats && g->Hof > 0 && g->Wof > 0 && (g->Ho - 1) * g->os + g->oh0 < g->Hof && (g->Wo - 1) * g->os + g->ow0 < g->Wof),
                 "capmi_igemm_nt: bad output-scatter geometry");
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.bn_mean = nullptr; a.bn_a = nullptr; a.addend = addend; a.ysaved = ysaved; a.stats = stats;
+    a.in_mean = nullptr; a.in_a = nullptr; a.in_off = nullptr; a.in_act = 0;
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldw = ldw; a.ldy = ldy; a.ld_addend = ld_addend; a.ld_saved = ld_saved;
     a.g = *g; a.act = act; a.dact = dact; a.out_f32 = out_f32;
@@ -1878,6 +1988,18 @@ static bool nt_halo3_ok(const IGemmArgs& a, const capmi_conv_geom* g, int nred) 
            g->os <= 1 && g->Wi <= 56 && g->Wi * g->Hi > 64 && g->Cin % 32 == 0 && a.K == 9 * g->Cin && a.N >= 32;       // (7 x 7: the k-group kernel is faster)
 }
 
+// Which kernel family applies batch norm + ReLU in the operand path for this convolution: 1 = the halo-staged 3x3 kernel
+// (transform of the halo tile in LDS), 2 = the LDS-DMA kernel on a 1x1 convolution (transform of the A fragments), 0 = none.
+// Same tile selection as the plain call, so the statistics parts (capmi_igemm_nt_stats_part_rows) keep their height.
+static int nt_inbn_kind(const IGemmArgs& a, const capmi_conv_geom* g, const NtCfg& c, int nred, int dtype) {
+    if (dtype != CAPMI_BF16 || nred || g->Cin > INBN_KMAX || g->Cin % 32 != 0 || g->ldx != g->Cin) return 0;
+    if (nt_halo3_ok(a, g, nred)) return 1;
+    const bool lin = g->kh == 1 && g->kw == 1 && g->up == 1 && g->pad == 0 && (g->Ho - 1) * g->sd < g->Hi && (g->Wo - 1) * g->sd < g->Wi;
+    const bool glds = c.wmw == 5 || c.bn == 128;
+    if (lin && glds && g->os <= 1 && a.K == g->Cin) return 2;
+    return 0;
+}
+
 static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, float* stats, int nred, int dtype, hipStream_t st) {
     if (nt_uses_skinny(g, a.M, a.K, stats != nullptr, dtype)) {
         CAPMI_CHECK(nred == 0, "capmi_igemm_nt_bnred: not available for M <= 64 plain products (see capmi_igemm_nt_bnred_part_rows)");
@@ -1888,6 +2010,27 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
         return 0;
     }
     const NtCfg c = nt_cfg(a.M, N, a.K, dtype);
+    if (a.in_a) {               // operand-path batch norm (capmi_igemm_nt_bnact): the two kernel families that carry it
+        const int kind = nt_inbn_kind(a, g, c, nred, dtype);
+        CAPMI_CHECK(kind != 0, "capmi_igemm_nt_bnact: this convolution has no operand-path batch-norm kernel (capmi_igemm_nt_bnact_supported)");
+        const int bn = kind == 1 ? (N <= 64 ? 64 : 128) : (c.wmw == 5 ? 64 : 128);
+        const int bm = kind == 1 ? c.bm : (c.wmw == 5 ? 64 : c.bm);
+        const int64_t tiles = (int64_t)cdiv(a.M, bm) * cdiv(N, bn);
+        CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt_bnact: grid too large");
+        const dim3 grid((unsigned)tiles);
+        if (kind == 1) {
+            if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, true>), grid, dim3(256), 0, st, a);
+            else if (bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, true>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, true>), grid, dim3(256), 0, st, a);
+        } else {
+            if (bm == 128) hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<128, 128>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<64, 128>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<64, 64>), grid, dim3(256), 0, st, a);
+        }
+        CAPMI_LAUNCH_CHECK("capmi_igemm_nt_bnact");
+        return 0;
+    }
     if (dtype == CAPMI_BF16 && nt_halo3_ok(a, g, nred)) {
         // same row-block height as the kernel it replaces: capmi_igemm_nt_stats_part_rows (one statistics part per BM rows) stays valid
         const int bn = N <= 64 ? 64 : 128;
@@ -1948,6 +2091,31 @@ extern "C" int capmi_igemm_nt_bn(const void* x, const void* w, void* y, const ca
     a.bn_mean = mean;
     a.bn_a = coef_a;
     return nt_dispatch(a, g, N, nullptr, 0, dtype, (hipStream_t)stream);
+}
+
+/* Convolution whose INPUT is the raw output of the producing convolution: act(coef_a * (x - mean) + offset) -- bn_apply's
+ * formula and rounding -- is applied in the A-operand path, so the producer's normalised / activated tensor is never
+ * materialised for this consumer (IC/model/MobileNetV2.py:88-121: the conv1 -> conv2 -> conv3 links of a unit chain).
+ * stats: fused batch statistics of THIS convolution's output, as capmi_igemm_nt. */
+extern "C" int capmi_igemm_nt_bnact_supported(const capmi_conv_geom* g, int N, int dtype) {
+    if (!g || dtype != CAPMI_BF16) return 0;
+    IGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
+    a.stats = reinterpret_cast<float*>(1);        // (a forward call: CAPMI_HALO3=2 / 3 look at it)
+    if (nt_uses_skinny(g, a.M, a.K, true, dtype)) return 0;
+    return nt_inbn_kind(a, g, nt_cfg(a.M, N, a.K, dtype), 0, dtype);
+}
+extern "C" int capmi_igemm_nt_bnact(const void* x_raw, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                                    const float* in_mean, const float* in_coef_a, const float* in_offset, int in_act,
+                                    float* stats, int dtype, void* stream) {
+    CAPMI_CHECK(in_mean && in_coef_a && in_offset, "capmi_igemm_nt_bnact: null batch-norm vector");
+    CAPMI_CHECK(in_act == CAPMI_ACT_RELU || in_act == CAPMI_ACT_RELU6, "capmi_igemm_nt_bnact: the input activation must be relu or relu6 (got %d)", in_act);
+    CAPMI_CHECK(((uintptr_t)in_mean | (uintptr_t)in_coef_a | (uintptr_t)in_offset) % 16 == 0, "capmi_igemm_nt_bnact: batch-norm vectors must be 16-byte aligned");
+    IGemmArgs a;
+    if (nt_prepare(a, x_raw, w, y, g, N, ldw, ldy, nullptr, nullptr, 0, nullptr, 0, stats, 0, 0, 0, 0, nullptr, dtype)) return 1;
+    a.in_mean = in_mean; a.in_a = in_coef_a; a.in_off = in_offset; a.in_act = in_act;
+    return nt_dispatch(a, g, N, stats, 0, dtype, (hipStream_t)stream);
 }
 
 extern "C" int capmi_igemm_nt_bnred_part_rows(const capmi_conv_geom* g, int N, int dtype) {

@@ -55,6 +55,7 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_igemm_nt),
     CAPMI_ENTRY(capmi_igemm_nt_group),
     CAPMI_ENTRY(capmi_igemm_nt_bn),
+    CAPMI_ENTRY(capmi_igemm_nt_bnact),
     CAPMI_ENTRY(capmi_igemm_nt_bnred),
     CAPMI_ENTRY(capmi_igemm_tn_wgrad),
     CAPMI_ENTRY(capmi_colsum),

@@ -160,6 +160,25 @@ class EncoderRunner:
         self.stem_hb, self.stem_wb = h + (stem.k - 1) // 2, w + (stem.k - 1) // 2
         self.s2d = z((B, self.stem_hb, self.stem_wb, self.stem_cs))
         self.out_id = enc.out
+        # ---- batch norm in the consumer's operand path (capmi_igemm_nt_bnact): a conv whose input tensor is produced by a
+        # conv -> batch_norm -> relu unit and read by nobody else multiplies the producer's RAW output, normalised and
+        # activated in its A-operand path -- the producer's bn_apply leaves the forward chain (MobileNetV2.py:88-121: the
+        # conv1 -> conv2 -> conv3 links of a bottleneck / inverted-residual unit).  The backward pass still reads the
+        # activated tensor (weight-gradient operand, ReLU mask): it is written on the side lane, under the decoder.
+        self.inbn = {}                   # id(consumer op) -> producer op
+        self.inbn_tensors = set()        # tensors whose main-lane bn_apply is gone
+        if dtype_code == 1 and os.environ.get('CAPMI_INBN', '1') != '0':
+            for op in enc.ops:
+                if not isinstance(op, arch.ConvBN) or id(op) in self.skipped or op.groups != 1 or op.src == 0:
+                    continue
+                P = producer.get(op.src)
+                if not isinstance(P, arch.ConvBN) or P.act not in ('relu', 'relu6') or P.dst in self.fused_add or consumers.get(op.src, 0) != 1:
+                    continue
+                if op.src == self.out_id:
+                    continue
+                if lib().capmi_igemm_nt_bnact_supported(self._conv_geom(op), op.cout, dtype_code) > 0:
+                    self.inbn[id(op)] = P
+                    self.inbn_tensors.add(P.dst)
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -216,6 +235,7 @@ class EncoderRunner:
                             _p(self.bn[o.dst]['mean']), _p(self.bn[o.dst]['a']), c)
             self.coef_jobs = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(self.dev)
             plan.add('capmi_bn_inference_coef_batched', _p(self.coef_jobs), len(convs), int(table[:, 5].max()), BN_EPS)
+        deferred = []               # bn_apply launches moved off the forward chain (operand-path batch norm)
         for op in self.enc.ops:
             if id(op) in self.skipped:
                 continue
@@ -258,6 +278,12 @@ class EncoderRunner:
                     plan.add('capmi_dwconv3x3_fwd', _p(self.act[op.src]), _p(w), _p(raw), B, hi, wi, c, op.stride, ho, wo, code)
                     if not is_test:
                         plan.add('capmi_bn_stats', _p(raw), M, c, _p(bn['stats']), code)
+                elif id(op) in self.inbn and not is_test:
+                    # the input is the producer's RAW output; its batch norm + activation ride in the A-operand path
+                    P = self.inbn[id(op)]
+                    pb = self.bn[P.dst]
+                    plan.add('capmi_igemm_nt_bnact', _p(self.raw[P.dst]), _p(w), _p(raw), self._conv_geom(op), c, op.k * op.k * op.cin, c,
+                             _p(pb['mean']), _p(pb['a']), _p(st.view(P.name + '_bn_offset')), ACT_CODES[P.act], _p(bn['stats']), code, lane=ln)
                 else:
                     g = self._conv_geom(op)
                     K = op.k * op.k * op.cin
@@ -283,7 +309,11 @@ class EncoderRunner:
                                  _p(bn['mean']), _p(bn['invstd']), 1 if update_running else 0, _p(raw), res, out, act, code, lane=lane)
                     else:
                         plan.add('capmi_bn_apply', _p(raw), _p(bn['mean']), _p(bn['a']), offset, res, out, M, c, act, code, lane=lane)
-                if fa is None:
+                if fa is None and op.dst in self.inbn_tensors and not is_test:
+                    # consumed through capmi_igemm_nt_bnact: no bn_apply on the forward chain; the backward pass's copy of
+                    # the activated tensor is written on the side lane after the encoder (below)
+                    deferred.append((raw, bn, offset, self.act[op.dst], M, c, ACT_CODES[op.act]))
+                elif fa is None:
                     apply(None, _p(self.act[op.dst]), ACT_CODES[op.act], ln)
                     if ln:
                         plan.record(('fout', op.dst), 1)
@@ -300,6 +330,17 @@ class EncoderRunner:
                 ho, wo, _ = self.shape[op.dst]
                 plan.add('capmi_maxpool3x3s2_fwd', _p(self.act[op.src]), _p(self.act[op.dst]), _p(self.pool_idx[op.dst]),
                          B, hi, wi, c, ho, wo, code)
+        if deferred and self.need_backward:
+            # the activated tensors the backward pass reads (weight-gradient operand, ReLU mask of the data gradient): written on
+            # the side lane behind the encoder's last statistics, i.e. under the decoder's forward / backward pass
+            lane = 1 if self.overlap_forward else 0
+            if lane:
+                plan.record(('enc', 'statistics final'), 0)
+                plan.wait(('enc', 'statistics final'), 1)
+            for raw_t, bn_t, off_t, act_t, M_t, c_t, code_t in deferred:
+                plan.add('capmi_bn_apply', _p(raw_t), _p(bn_t['mean']), _p(bn_t['a']), off_t, None, _p(act_t), M_t, c_t, code_t, code, lane=lane)
+            if lane:
+                plan.record(('enc', 'deferred applies'), 1)
 
     # ------------------------------------------------------------------ backward plan
     def _backward_order(self):
@@ -354,6 +395,8 @@ class EncoderRunner:
         premasked = set()
         pending = {}                    # tensor -> buffer that holds its first gradient contribution (alias, not a copy)
         n_out = self.grad[self.out_id].numel()
+        if self.inbn_tensors:       # (a no-op when the forward plan was a launch of its own: plans end with their lanes joined)
+            plan.wait(('enc', 'deferred applies'), 0)
         if tensor_act.get(self.out_id) is not None:     # the decoder hands over d/d(post-activation): mask it once, in place
             plan.add('capmi_act_bwd', _p(self.grad[self.out_id]), _p(self.act[self.out_id]), _p(self.grad[self.out_id]), 0, n_out,
                      ACT_CODES[tensor_act[self.out_id]], code)

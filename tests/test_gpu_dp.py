@@ -153,7 +153,8 @@ def _cfg2_worker(port, q):
     assert dist.get_backend(pg) == 'nccl'
     cfg = default_cfg(batch_size=32, sample_count=0, **bench.WORKLOAD)
     eng = CaptionEngine(cfg, device='cuda:0', use_graph=True, process_group=pg)
-    trainer = dp.OverlappedTrainer(eng)                                 # default 32 MiB buckets, as bench.py --gpus N runs it
+    assert dp.OverlappedTrainer(eng).bucket_dtype == 'bf16'            # what bench.py --gpus N runs: a bf16 engine exchanges bf16 buckets
+    trainer = dp.OverlappedTrainer(eng, bucket_dtype='f32')             # default 32 MiB buckets; f32 payload: comparable bit for bit
     assert trainer.active
     assert trainer.native_comm is not None and trainer.native_comm.ok, getattr(trainer.native_comm, 'why', 'no native communicator')
     image, cap = bench.synthetic_batch(32, cfg, 1234)
@@ -162,7 +163,17 @@ def _cfg2_worker(port, q):
     trainer.check_sync()
     p = eng.export_reference_params()
     segs = trainer._progs[32]['segs']
-    q.put((losses, [(b, e) for _, (b, e), _ in segs], eng.store.trainable_size, 'step' in trainer._progs[32], p))
+    # the same three steps with the bf16 payload (capmi_cast -> capmi_allreduce_bucket_bf16 -> capmi_adam_g16) on a fresh engine
+    eng16 = CaptionEngine(cfg, device='cuda:0', use_graph=True, process_group=pg)
+    tr16 = dp.OverlappedTrainer(eng16, bucket_dtype='bf16')
+    assert tr16.native_comm is not None and tr16.native_comm.ok
+    losses16 = [float(tr16.train_step(image_d, cap_d)[0].cpu()[0]) for _ in range(3)]
+    tr16.check_sync()
+    names16 = [r[1] for r in tr16._progs[32]['step'].calls if r[0] is not None]
+    p16 = eng16.export_reference_params()
+    q.put((losses, [(b, e) for _, (b, e), _ in segs], eng.store.trainable_size, 'step' in trainer._progs[32], p,
+           losses16, names16.count('capmi_allreduce_bucket_bf16'), names16.count('capmi_adam_g16'),
+           {k: p16[k] for k in ('lstm_w', 'fc_11.w_0', 'word_embedding')}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -179,7 +190,7 @@ def test_configs2_resnet50_bf16_through_the_bucketed_rccl_path(deterministic):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     proc = ctx.Process(target=_cfg2_worker, args=(port, q))
     proc.start()
-    losses, ranges, total, native, params = q.get(timeout=1200)
+    losses, ranges, total, native, params, losses16, n_ar16, n_adam16, params16 = q.get(timeout=1200)
     proc.join(timeout=600)
     assert proc.exitcode == 0
     assert len(ranges) >= 4 and ranges[0][0] == 0 and ranges[-1][1] == total
@@ -199,6 +210,14 @@ def test_configs2_resnet50_bf16_through_the_bucketed_rccl_path(deterministic):
     assert any(np.abs(p[k] - p0[k]).max() > 0 for k in ('lstm_w', 'res_conv1_weights', 'res5_3_branch2c_weights'))
     for k in params:
         np.testing.assert_array_equal(p[k], params[k], err_msg=k)
+    # bf16 payload: every bucket went through the bf16 all-reduce and the bf16-gradient Adam; the first loss is the same
+    # forward pass, later steps stay within the bf16 bound and the decoder's parameters move with the f32-payload run
+    assert n_ar16 == len(ranges) and n_adam16 == len(ranges)
+    assert losses16[0] == want[0]
+    np.testing.assert_allclose(losses16, want, rtol=0, atol=5e-2)
+    for k in params16:
+        moved = np.linalg.norm(p[k] - p0[k])
+        assert np.linalg.norm(params16[k] - p[k]) <= 0.1 * moved, (k, np.linalg.norm(params16[k] - p[k]) / moved)
 
 
 # ------------------------------------------------------------------ train.py:121-139,172: the loop drives the data-parallel step

@@ -535,6 +535,67 @@ def test_conv_with_inference_batch_norm_in_the_epilogue(dtype, B, C, H, W, Co, k
     assert float(d) <= tol * max(1.0, float(Y2.float().abs().max())), float(d)
 
 
+@pytest.mark.parametrize('B,C,H,W,Co,k,act', [(4, 64, 56, 56, 64, 3, 'relu'),      # halo kernel, 64 x 64 tiles, two channel chunks
+                                               (8, 128, 28, 28, 128, 3, 'relu'),    # halo kernel, 128-wide tiles
+                                               (3, 32, 9, 11, 48, 3, 'relu6'),      # ragged rows, one chunk, relu6
+                                               (2, 256, 14, 14, 256, 3, 'relu'),
+                                               (4, 64, 56, 56, 256, 1, 'relu'),     # 1x1, K = 64 (two k-steps), 64 x 128 tiles
+                                               (16, 512, 7, 7, 2048, 1, 'relu'),    # 1x1, K = 512: the whole coefficient table
+                                               (64, 512, 7, 7, 2048, 1, 'relu'),    # the same at batch 64: 128 x 128 tiles
+                                               (5, 96, 10, 7, 40, 1, 'relu6'),      # 1x1, ragged M / N, 64 x 64 tiles
+                                               (8, 256, 14, 14, 1024, 1, 'relu')])
+def test_conv_with_batch_norm_in_the_operand_path(B, C, H, W, Co, k, act):
+    """capmi_igemm_nt_bnact (MobileNetV2.py:88-121: conv -> batch_norm -> relu -> conv): the consumer convolution reads the
+    producer's RAW output and applies its train-mode batch norm + activation in the A-operand path.  Against (i) the
+    oracle's batch_norm_fwd + activation + conv2d_fwd on the same raw tensor, and (ii) capmi_bn_apply followed by
+    capmi_igemm_nt -- the materialised path it replaces -- BIT FOR BIT, output and fused batch statistics alike."""
+    _lib, tdt, code = _env()
+    dtype = 'bf16'
+    rng = np.random.RandomState(B * C + Co + k)
+    raw = rnd(rng.standard_normal((B, C, H, W)) * rng.uniform(0.5, 2, (1, C, 1, 1)) + rng.standard_normal((1, C, 1, 1)), dtype)
+    w = rnd(rng.standard_normal((Co, C, k, k)) / np.sqrt(C * k * k), dtype)
+    scale, offset = rng.uniform(0.5, 1.5, C), rng.standard_normal(C) * 0.3
+    pad = 1 if k == 3 else 0
+    f32 = torch.float32
+    g = _lib.ConvGeom(B, H, W, C, H, W, k, k, 1, 1, pad, C)
+    kind = _lib.lib().capmi_igemm_nt_bnact_supported(g, Co, code[dtype])
+    assert kind == (1 if k == 3 else 2), kind
+    # the producer's statistics through the product path: bn_stats -> bn_finalize (mean, coef_a = scale * invstd)
+    M = B * H * W
+    RAW = dev(_nhwc(raw), tdt[dtype])
+    pr = _lib.lib().capmi_bn_stats_part_rows(M, C, code[dtype])
+    ws = torch.zeros(((M + pr - 1) // pr + 64, C, 2), dtype=f32, device=DEV)
+    SC, OF = dev(scale, f32), dev(offset, f32)
+    rm, rv = torch.zeros(C, dtype=f32, device=DEV), torch.ones(C, dtype=f32, device=DEV)
+    mean, invstd, ca = (torch.zeros(C, dtype=f32, device=DEV) for _ in range(3))
+    _lib.call('capmi_bn_stats', p(RAW), M, C, p(ws), code[dtype], stream())
+    _lib.call('capmi_bn_finalize', p(ws), pr, M, C, p(SC), p(rm), p(rv), 0.9, 1e-5, p(mean), p(invstd), p(ca), 1, stream())
+    Wk = dev(w.transpose(0, 2, 3, 1), tdt[dtype])
+    K = k * k * C
+    pr2 = _lib.lib().capmi_igemm_nt_stats_part_rows(M, Co, K, code[dtype])
+    np2 = (M + pr2 - 1) // pr2
+    st_f = torch.zeros((np2 + 64, Co, 2), dtype=f32, device=DEV)
+    st_m = torch.zeros((np2 + 64, Co, 2), dtype=f32, device=DEV)
+    Yf = torch.zeros((B, H, W, Co), dtype=tdt[dtype], device=DEV)
+    Ym = torch.zeros((B, H, W, Co), dtype=tdt[dtype], device=DEV)
+    ACTT = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+    ac = _lib.ACT_CODES[act]
+    _lib.call('capmi_igemm_nt_bnact', p(RAW), p(Wk), p(Yf), g, Co, K, Co, p(mean), p(ca), p(OF), ac, p(st_f), code[dtype], stream())
+    _lib.call('capmi_bn_apply', p(RAW), p(mean), p(ca), p(OF), None, p(ACTT), M, C, ac, code[dtype], stream())
+    _lib.call('capmi_igemm_nt', p(ACTT), p(Wk), p(Ym), g, Co, K, Co, None, None, 0, None, 0, p(st_m), 0, 0, 0, code[dtype], stream())
+    torch.cuda.synchronize()
+    assert torch.equal(Yf, Ym), 'fused operand path differs from bn_apply + conv in %d elements' % int((Yf != Ym).sum())
+    assert torch.equal(st_f[:np2], st_m[:np2])
+    # oracle: train-mode batch norm of the raw tensor -> activation -> (rounded to the storage type, as the product stores it) -> conv
+    yb, _, _ = O.batch_norm_fwd(raw, scale, offset, np.zeros(C), np.ones(C))
+    a_ = rnd(O.relu6(yb) if act == 'relu6' else O.relu(yb), dtype)
+    want = O.conv2d_fwd(a_, w, 1, pad)
+    got = host(Yf)
+    err = np.linalg.norm(got - _nhwc(want)) / np.linalg.norm(want)
+    assert err <= 1.5e-2, err        # bf16 output rounding (2^-9 relative per element) + the activations' own rounding flips
+    check(got, _nhwc(want), dtype, name='conv on bn(raw)')
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 def test_lstm_cell_sentinel_embedding(dtype):
     _lib, tdt, code = _env()
