@@ -222,6 +222,17 @@ int capmi_bn_finalize(float* ws, int part_rows, int M, int C, const float* scale
                       int update_running, void* stream);
 int capmi_bn_apply(const void* x, const float* saved_mean, const float* coef_a, const float* offset,
                    const void* res, void* y, int M, int C, int act, int dtype, void* stream);
+/* capmi_bn_bwd_reduce / capmi_bn_bwd_apply without the dependent second-stage launch between them (~50 per train step, ~9 us
+ * each on the critical chain): the reduction ADDS its block totals (f32 atomics; a wave instruction covers 256 contiguous
+ * bytes, at most 1/8 of the grid per address) into eight accumulator rows acc8[8][2C] -- zeroed by the caller once per
+ * step, 16-byte aligned -- and the apply kernel sums the rows in its prologue and adds the result to red
+ * ([d offset | d scale]).  The summation order inside a row is not fixed: in deterministic mode (capmi_deterministic) both
+ * calls run the two-stage form through ws / red instead, which is why they take both sets of buffers. */
+int capmi_bn_bwd_reduce_spread(const void* dy, const void* x, const void* y, const float* saved_mean, const float* saved_invstd,
+                               float* ws, float* red, float* acc8, int M, int C, int act, int dtype, void* stream);
+int capmi_bn_bwd_apply_spread(const void* dy, const void* x, const void* y, const float* saved_mean, const float* saved_invstd,
+                              const float* scale, float* red, const float* acc8, void* dx, int dx_accumulate, void* dres,
+                              int dres_accumulate, int M, int C, int act, int dtype, void* stream);
 /* Inference mode (fluid batch_norm is_test=True, the exported model of infer.py): mean = running mean,
  * coef_a = scale / sqrt(running variance + eps); follow with capmi_bn_apply. */
 int capmi_bn_inference_coef(const float* scale, const float* run_mean, const float* run_var, float eps, float* mean,

@@ -518,7 +518,12 @@ extern "C" int capmi_bn_apply(const void* x, const float* saved_mean, const floa
 // ACT is a template parameter and the loads of U rows are issued as one batch before any arithmetic: with a run-time
 // activation switch the loop compiled to a branch per element and 2-3 loads in flight per thread -- 2.8 TB/s on
 // cold tensors in the model (5.7 alone on MALL-warm ones), the largest kernel family on the main lane.
-template <typename T, int ACT>
+// SPREAD: no second stage.  The block totals go out as f32 atomics into EIGHT accumulator rows acc8[8][2C] (row = workgroup
+// index mod 8: at most a sixteenth of the grid adds to any one address, and a wave instruction covers 256 contiguous
+// bytes -- the memory-side atomic units' full rate, MI355X_MICROARCH.md); bn_bwd_apply sums the eight rows in its prologue.
+// The dependent ~9 us second-stage launch behind every one of the ~50 reductions of a step is gone; the price is the
+// summation order of a row (not fixed): capmi_deterministic() keeps the two-stage form.
+template <typename T, int ACT, bool SPREAD = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, float* ws,
                                                             int M, int C, ColLayout L) {
@@ -585,10 +590,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     }
     block_col_reduce<VEC>(part, a1, cc, rr, L, active);
     block_col_reduce<VEC>(part, a2, cc, rr, L, active);
-    if (active && rr == 0) {
-        float* w = ws + (int64_t)blockIdx.x * 2 * C + chunk * VEC;
+    if constexpr (SPREAD) {
+        // block totals -> LDS -> one atomic per thread and entry, 64 lanes on 64 consecutive floats
+        __syncthreads();
+        const int ncol = L.cpc * VEC;                       // columns of this column block (<= 256 * VEC floats of `part` = 2 x ncol for cpc <= 128)
+        float* tot = part;
+        if (active && rr == 0) {
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) { w[v] = a1[v]; w[C + v] = a2[v]; }
+            for (int v = 0; v < VEC; ++v) tot[cc * VEC + v] = a1[v];
+        }
+        __syncthreads();
+        float* row = ws + (int64_t)(blockIdx.x & 7) * 2 * C + (int64_t)blockIdx.y * ncol;
+        for (int i = tid; i < ncol; i += 256)
+            if (blockIdx.y * ncol + i < C) __hip_atomic_fetch_add(row + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (active && rr == 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) tot[cc * VEC + v] = a2[v];
+        }
+        __syncthreads();
+        for (int i = tid; i < ncol; i += 256)
+            if (blockIdx.y * ncol + i < C) __hip_atomic_fetch_add(row + C + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (active && rr == 0) {
+            float* w = ws + (int64_t)blockIdx.x * 2 * C + chunk * VEC;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) { w[v] = a1[v]; w[C + v] = a2[v]; }
+        }
     }
 }
 
@@ -633,13 +661,13 @@ extern "C" int capmi_bn_bwd_reduce_final(const float* ws, int nparts, int C, flo
     return 0;
 }
 
-template <typename T>
+template <typename T, bool SPREAD = false>
 static int bwd_reduce_launch(int act, int gx, int gy, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean, const float* invstd,
                              float* ws, int M, int C, const ColLayout& L) {
     switch (act) {
-        case CAPMI_ACT_NONE: hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, CAPMI_ACT_NONE>), dim3(gx, gy), dim3(256), 0, st, dy, x, y, mean, invstd, ws, M, C, L); return 0;
-        case CAPMI_ACT_RELU: hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, CAPMI_ACT_RELU>), dim3(gx, gy), dim3(256), 0, st, dy, x, y, mean, invstd, ws, M, C, L); return 0;
-        case CAPMI_ACT_RELU6: hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, CAPMI_ACT_RELU6>), dim3(gx, gy), dim3(256), 0, st, dy, x, y, mean, invstd, ws, M, C, L); return 0;
+        case CAPMI_ACT_NONE: hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, CAPMI_ACT_NONE, SPREAD>), dim3(gx, gy), dim3(256), 0, st, dy, x, y, mean, invstd, ws, M, C, L); return 0;
+        case CAPMI_ACT_RELU: hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, CAPMI_ACT_RELU, SPREAD>), dim3(gx, gy), dim3(256), 0, st, dy, x, y, mean, invstd, ws, M, C, L); return 0;
+        case CAPMI_ACT_RELU6: hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, CAPMI_ACT_RELU6, SPREAD>), dim3(gx, gy), dim3(256), 0, st, dy, x, y, mean, invstd, ws, M, C, L); return 0;
     }
     capmi_set_error("capmi_bn_bwd_reduce: unsupported activation %d", act);
     return 1;
@@ -678,15 +706,37 @@ extern "C" int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y,
     return 0;
 }
 
+/* capmi_bn_bwd_reduce without its second stage: the block totals are ADDED (f32 atomics) into acc8[8][2C], which the caller
+ * zeroes once per step and hands to capmi_bn_bwd_apply_spread -- that kernel sums the eight rows in its prologue and adds
+ * the result to `red` ([d offset | d scale]).  In deterministic mode (capmi.h) the pair falls back to the two-stage form
+ * through ws / red, so both entry points take both sets of buffers. */
+extern "C" int capmi_bn_bwd_reduce_spread(const void* dy, const void* x, const void* y, const float* saved_mean, const float* saved_invstd,
+                                          float* ws, float* red, float* acc8, int M, int C, int act, int dtype, void* stream) {
+    CAPMI_CHECK(acc8, "capmi_bn_bwd_reduce_spread: null accumulator");
+    if (capmi_deterministic()) return capmi_bn_bwd_reduce(dy, x, y, saved_mean, saved_invstd, ws, red, M, C, act, dtype, stream);
+    CAPMI_CHECK(dy && x && saved_mean && saved_invstd, "capmi_bn_bwd_reduce_spread: null pointer");
+    CAPMI_CHECK(!act || y, "capmi_bn_bwd_reduce_spread: activation mask needs y");
+    int gx = 0, gy = 0;
+    CAPMI_DISPATCH(dtype, "capmi_bn_bwd_reduce_spread", {
+        CAPMI_CHECK(C % Vec<T>::N == 0, "capmi_bn_bwd_reduce_spread: C=%d not a multiple of %d", C, Vec<T>::N);
+        ColLayout L = bwd_reduce_layout(M, C, Vec<T>::N, &gx, &gy);
+        if (bwd_reduce_launch<T, true>(act, gx, gy, (hipStream_t)stream, (const T*)dy, (const T*)x, (const T*)y, saved_mean, saved_invstd, acc8, M, C, L)) return 1;
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bn_bwd_reduce_spread");
+    return 0;
+}
+
 // dx (+)= k1 * ((dz - m0) - (x - mu)*c2),  k1 = s*is, m0 = red0/M, c2 = is*red1/M;  dres (+)= dz.
 // Both differences are formed BEFORE scaling: a spatially uniform dz (e.g. the reference's
 // singleton attention) makes dz - mean(dz) cancel almost completely.
 // ACT: compile-time activation of the layer's output (none / relu / relu6); DRES: 0 = no residual gradient, 1 = store
 // dz, 2 = accumulate dz; DXACC: dx accumulates.  Batched loads as in bn_bwd_reduce_kernel.
+// acc8 != NULL (capmi_bn_bwd_apply_spread): the sums are the eight accumulator rows of capmi_bn_bwd_reduce_spread, added up
+// here in row order; the first row block also adds them to `red` (one writer per channel).
 template <typename T, int ACT, int DRES, bool DXACC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ scale, const float* __restrict__ red, T* dx,
+                                                           const float* __restrict__ scale, float* red, const float* __restrict__ acc8, T* dx,
                                                            T* dres, int M, int C, float inv_m, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
     constexpr int U = (ACT ? 1 : 0) + (DRES == 2 ? 1 : 0) + (DXACC ? 1 : 0) >= 2 ? 2 : 4;      // register budget
@@ -703,8 +753,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         is_[v] = invstd[c];
         sc_[v] = scale[c];
         mu[v] = mean[c];
-        r0_[v] = red[c];
-        r1_[v] = red[C + c];
+        if (!acc8) {
+            r0_[v] = red[c];
+            r1_[v] = red[C + c];
+        }
+    }
+    if (acc8) {         // 2 x 8 rows x VEC floats as 16-byte loads, all in flight together
+        f32x4 t0[8][VEC / 4], t1[8][VEC / 4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                t0[j][q] = *reinterpret_cast<const f32x4*>(acc8 + (int64_t)j * 2 * C + chunk * VEC + 4 * q);
+                t1[j][q] = *reinterpret_cast<const f32x4*>(acc8 + (int64_t)j * 2 * C + C + chunk * VEC + 4 * q);
+            }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s0 += t0[j][v / 4][v % 4]; s1 += t1[j][v / 4][v % 4]; }
+            r0_[v] = s0;
+            r1_[v] = s1;
+        }
+        if (blockIdx.x == 0 && rr == 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int c = chunk * VEC + v;
+                red[c] += r0_[v];
+                red[C + c] += r1_[v];
+            }
+        }
     }
     const int m_begin = blockIdx.x * L.rows_per_block;
     const int m_end = min(M, m_begin + L.rows_per_block);
@@ -768,32 +846,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 template <typename T, int ACT, int DRES>
 static void bn_bwd_apply_launch2(bool dxacc, dim3 grid, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean, const float* invstd,
-                                 const float* scale, const float* red, T* dx, T* dres, int M, int C, const ColLayout& L) {
-    if (dxacc) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, true>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, 1.f / (float)M, L);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, false>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, 1.f / (float)M, L);
+                                 const float* scale, float* red, const float* acc8, T* dx, T* dres, int M, int C, const ColLayout& L) {
+    if (dxacc) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, true>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, 1.f / (float)M, L);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, false>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, 1.f / (float)M, L);
 }
 template <typename T, int ACT>
 static void bn_bwd_apply_launch1(int dres_mode, bool dxacc, dim3 grid, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean,
-                                 const float* invstd, const float* scale, const float* red, T* dx, T* dres, int M, int C, const ColLayout& L) {
-    if (dres_mode == 0) bn_bwd_apply_launch2<T, ACT, 0>(dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L);
-    else if (dres_mode == 1) bn_bwd_apply_launch2<T, ACT, 1>(dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L);
-    else bn_bwd_apply_launch2<T, ACT, 2>(dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L);
+                                 const float* invstd, const float* scale, float* red, const float* acc8, T* dx, T* dres, int M, int C, const ColLayout& L) {
+    if (dres_mode == 0) bn_bwd_apply_launch2<T, ACT, 0>(dxacc, grid, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, L);
+    else if (dres_mode == 1) bn_bwd_apply_launch2<T, ACT, 1>(dxacc, grid, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, L);
+    else bn_bwd_apply_launch2<T, ACT, 2>(dxacc, grid, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, L);
 }
 template <typename T>
 static int bn_bwd_apply_launch(int act, int dres_mode, bool dxacc, dim3 grid, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean,
-                               const float* invstd, const float* scale, const float* red, T* dx, T* dres, int M, int C, const ColLayout& L) {
+                               const float* invstd, const float* scale, float* red, const float* acc8, T* dx, T* dres, int M, int C, const ColLayout& L) {
     switch (act) {
-        case CAPMI_ACT_NONE: bn_bwd_apply_launch1<T, CAPMI_ACT_NONE>(dres_mode, dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L); return 0;
-        case CAPMI_ACT_RELU: bn_bwd_apply_launch1<T, CAPMI_ACT_RELU>(dres_mode, dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L); return 0;
-        case CAPMI_ACT_RELU6: bn_bwd_apply_launch1<T, CAPMI_ACT_RELU6>(dres_mode, dxacc, grid, st, dy, x, y, mean, invstd, scale, red, dx, dres, M, C, L); return 0;
+        case CAPMI_ACT_NONE: bn_bwd_apply_launch1<T, CAPMI_ACT_NONE>(dres_mode, dxacc, grid, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, L); return 0;
+        case CAPMI_ACT_RELU: bn_bwd_apply_launch1<T, CAPMI_ACT_RELU>(dres_mode, dxacc, grid, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, L); return 0;
+        case CAPMI_ACT_RELU6: bn_bwd_apply_launch1<T, CAPMI_ACT_RELU6>(dres_mode, dxacc, grid, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, L); return 0;
     }
     capmi_set_error("capmi_bn_bwd_apply: unsupported activation %d", act);
     return 1;
 }
 
-extern "C" int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, const float* saved_mean, const float* saved_invstd,
-                                  const float* scale, const float* red, void* dx, int dx_accumulate, void* dres, int dres_accumulate,
-                                  int M, int C, int act, int dtype, void* stream) {
+static int bn_bwd_apply_impl(const void* dy, const void* x, const void* y, const float* saved_mean, const float* saved_invstd,
+                             const float* scale, float* red, const float* acc8, void* dx, int dx_accumulate, void* dres, int dres_accumulate,
+                             int M, int C, int act, int dtype, void* stream) {
     CAPMI_CHECK(dy && x && saved_mean && saved_invstd && scale && red && dx, "capmi_bn_bwd_apply: null pointer");
     CAPMI_CHECK(!act || y, "capmi_bn_bwd_apply: activation mask needs y");
     CAPMI_DISPATCH(dtype, "capmi_bn_bwd_apply", {
@@ -801,8 +879,23 @@ extern "C" int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, 
         int gx, gy;
         ColLayout L = ew_layout(M, C, Vec<T>::N, &gx, &gy);
         if (bn_bwd_apply_launch<T>(act, dres ? (dres_accumulate ? 2 : 1) : 0, dx_accumulate != 0, dim3(gx, gy), (hipStream_t)stream, (const T*)dy,
-                                   (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, red, (T*)dx, (T*)dres, M, C, L)) return 1;
+                                   (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, red, acc8, (T*)dx, (T*)dres, M, C, L)) return 1;
     });
     CAPMI_LAUNCH_CHECK("capmi_bn_bwd_apply");
     return 0;
+}
+extern "C" int capmi_bn_bwd_apply(const void* dy, const void* x, const void* y, const float* saved_mean, const float* saved_invstd,
+                                  const float* scale, const float* red, void* dx, int dx_accumulate, void* dres, int dres_accumulate,
+                                  int M, int C, int act, int dtype, void* stream) {
+    return bn_bwd_apply_impl(dy, x, y, saved_mean, saved_invstd, scale, const_cast<float*>(red), nullptr, dx, dx_accumulate, dres, dres_accumulate,
+                             M, C, act, dtype, stream);
+}
+/* The consumer of capmi_bn_bwd_reduce_spread: the channel sums are the eight rows of acc8 (summed in row order in the
+ * kernel's prologue); the first row block adds them to red ([d offset | d scale]).  Deterministic mode: capmi_bn_bwd_apply. */
+extern "C" int capmi_bn_bwd_apply_spread(const void* dy, const void* x, const void* y, const float* saved_mean, const float* saved_invstd,
+                                         const float* scale, float* red, const float* acc8, void* dx, int dx_accumulate, void* dres,
+                                         int dres_accumulate, int M, int C, int act, int dtype, void* stream) {
+    CAPMI_CHECK(acc8 && ((uintptr_t)acc8 % 16 == 0) && C % 4 == 0, "capmi_bn_bwd_apply_spread: acc8 must be 16-byte aligned (and C a multiple of 4)");
+    return bn_bwd_apply_impl(dy, x, y, saved_mean, saved_invstd, scale, red, capmi_deterministic() ? nullptr : acc8, dx, dx_accumulate, dres,
+                             dres_accumulate, M, C, act, dtype, stream);
 }

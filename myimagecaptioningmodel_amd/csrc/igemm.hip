@@ -296,30 +296,40 @@ template <int TN> __device__ __forceinline__ void dact_run(float (&v)[TN], const
 // ------------------------------------------------------------------ batch norm + activation on 8 bf16 operand values
 // The formula and rounding points of bn_apply_kernel (bn_ops.hip): act(a * (x - mean) + offset) in f32, rounded to bf16
 // once -- a consumer that applies it to the RAW conv output multiplies the bits bn_apply would have stored.
-// ca / mu / of: this lane's 8 consecutive channels.  fmaxf(NaN, 0) = 0: a NaN operand (the padding page of the fused
-// weight gradient) comes out as an exact zero.
+// ca / mu / of: this lane's 8 consecutive channels.
 constexpr int INBN_KMAX = 512;          // channels of the input tensor the coefficient table in LDS holds
 __device__ __forceinline__ bf16x8 bn_act8(bf16x8 v, const f32x4& ca0, const f32x4& ca1, const f32x4& mu0, const f32x4& mu1,
                                           const f32x4& of0, const f32x4& of1, int act) {
     bf16x8 o;
+    const float hi = act == CAPMI_ACT_RELU6 ? 6.f : __builtin_inff();
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float a = e < 4 ? ca0[e & 3] : ca1[e & 3], m = e < 4 ? mu0[e & 3] : mu1[e & 3], b = e < 4 ? of0[e & 3] : of1[e & 3];
-        float f = a * ((float)v[e] - m) + b;
-        f = fmaxf(f, 0.f);
-        if (act == CAPMI_ACT_RELU6) f = fminf(f, 6.f);
-        o[e] = (bf16)f;
+        const float f = a * ((float)v[e] - m) + b;
+        o[e] = (bf16)__builtin_amdgcn_fmed3f(f, 0.f, hi);       // relu / relu6 as ONE instruction (median of f, 0, upper bound)
     }
     return o;
 }
 // the coefficient table [3][INBN_KMAX] f32 (a | mean | offset) of an input tensor with C channels: plain loads + LDS stores
 // by the first C / 4 threads; the caller orders them before the first read (lgkmcnt(0) + a workgroup barrier)
+template <int KC>
 __device__ __forceinline__ void inbn_load_table(float* tab, const IGemmArgs& a, int C, int tid) {
     if (tid * 4 < C) {
         *reinterpret_cast<f32x4*>(tab + tid * 4) = *reinterpret_cast<const f32x4*>(a.in_a + tid * 4);
-        *reinterpret_cast<f32x4*>(tab + INBN_KMAX + tid * 4) = *reinterpret_cast<const f32x4*>(a.in_mean + tid * 4);
-        *reinterpret_cast<f32x4*>(tab + 2 * INBN_KMAX + tid * 4) = *reinterpret_cast<const f32x4*>(a.in_off + tid * 4);
+        *reinterpret_cast<f32x4*>(tab + KC + tid * 4) = *reinterpret_cast<const f32x4*>(a.in_mean + tid * 4);
+        *reinterpret_cast<f32x4*>(tab + 2 * KC + tid * 4) = *reinterpret_cast<const f32x4*>(a.in_off + tid * 4);
     }
+}
+// this lane's 8 channels c0 .. c0 + 7 of the table: (a | mean | offset) as six 16-byte LDS reads
+template <int KC>
+__device__ __forceinline__ void inbn_coef(const float* tab, int c0, f32x4 (&cf)[6]) {
+    const float* t = tab + c0;
+    cf[0] = *reinterpret_cast<const f32x4*>(t);
+    cf[1] = *reinterpret_cast<const f32x4*>(t + 4);
+    cf[2] = *reinterpret_cast<const f32x4*>(t + KC);
+    cf[3] = *reinterpret_cast<const f32x4*>(t + KC + 4);
+    cf[4] = *reinterpret_cast<const f32x4*>(t + 2 * KC);
+    cf[5] = *reinterpret_cast<const f32x4*>(t + 2 * KC + 4);
 }
 
 // ------------------------------------------------------------------ shared epilogue of the tiled NT kernels
@@ -721,9 +731,10 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // (MobileNetV2.py:88-121: conv -> batch_norm -> relu is ONE unit of the reference graph; the unit boundary moves from
 // the producer's output to the consumer's operand).  With 4x1 waves every A row belongs to one wave, so the transform runs
 // once per staged element; per-channel coefficients come from a table in LDS.
-template <int BM, int BN, int NST, bool RED, int LIN, int KG = 1, bool INBN = false>
+template <int BM, int BN, int NST, bool RED, int LIN, int KG = 1, int INBN_KC = 0>        // INBN_KC: channels the coefficient table holds (0: off)
 __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int nblocks) {
     typedef bf16 T;
+    constexpr bool INBN = INBN_KC > 0;
     static_assert(!INBN || (LIN == 1 && KG == 1 && !RED), "operand-path batch norm: 1x1 convolutions on the plain kernel");
     constexpr int BK = 32, WMW = 4;
     constexpr int TM = BM / 64, TN = BN / 16;           // 4x1 waves: BM/4 rows x BN columns each
@@ -732,7 +743,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     constexpr int ACNT = BM / 64, BCNT = BN / 64;       // DMA instructions per thread per stage
     constexpr int NGL = ACNT + BCNT;
     __shared__ __attribute__((aligned(1024))) char smem[NST * KG * STB < 4096 ? 4096 : NST * KG * STB];
-    __shared__ __attribute__((aligned(16))) float inbn_tab[INBN ? 3 * INBN_KMAX : 4];
+    __shared__ __attribute__((aligned(16))) float inbn_tab[INBN ? 3 * INBN_KC : 4];
 
     const T* __restrict__ X = (const T*)a.x;
     const T* __restrict__ W = (const T*)a.w;
@@ -831,7 +842,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     for (int p = 0; p < NST - 1; ++p)
         if (!(CAPMI_NT_ABL & 4)) issue_stage(p);
     if constexpr (INBN) {       // behind the prologue's DMA issues: the table's own load latency hides under them; published by the
-        inbn_load_table(inbn_tab, a, a.K, tid);                  // first k-step's barrier
+        inbn_load_table<INBN ? INBN_KC : 4>(inbn_tab, a, a.K, tid);      // first k-step's barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     int slot = 0;                                            // ring slot of stage kt
@@ -850,15 +861,8 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j].load(reinterpret_cast<const T*>(st + boff[j]));
         f32x4 cf[INBN ? 6 : 1];
-        if constexpr (INBN) {   // this lane's 8 channels of the k-step: kt * 32 + 8 fg .. + 7 (16-lane groups read the same words: broadcast)
-            const float* t = inbn_tab + kt * BK + fg * 8;
-            cf[0] = *reinterpret_cast<const f32x4*>(t);
-            cf[1] = *reinterpret_cast<const f32x4*>(t + 4);
-            cf[2] = *reinterpret_cast<const f32x4*>(t + INBN_KMAX);
-            cf[3] = *reinterpret_cast<const f32x4*>(t + INBN_KMAX + 4);
-            cf[4] = *reinterpret_cast<const f32x4*>(t + 2 * INBN_KMAX);
-            cf[5] = *reinterpret_cast<const f32x4*>(t + 2 * INBN_KMAX + 4);
-        }
+        if constexpr (INBN)     // this lane's 8 channels of the k-step: kt * 32 + 8 fg .. + 7 (16-lane groups read the same words: broadcast)
+            inbn_coef<INBN ? INBN_KC : 4>(inbn_tab, kt * BK + fg * 8, cf);
         // every fragment read is issued before the first MFMA: one exposed LDS latency per k-step instead of one
         // per pair of MFMAs (the scheduler otherwise recycles two fragment registers; grids below ~2 waves per
         // SIMD have nobody to hide that behind)
@@ -910,9 +914,11 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
 }
 
 // 1x1 convolution whose input is the producer's RAW output: batch norm + ReLU in the A-operand path (nt_glds_body, INBN)
-template <int BM, int BN>
-__global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_glds_inbn_kernel(IGemmArgs a) {
-    nt_glds_body<BM, BN, 3, false, 1, 1, true>(a, blockIdx.x, gridDim.x);
+// (KC = 128 / 256 / 512: the table is sized to the layer -- 1.5 / 3 / 6 KB next to a 36 KB ring keeps 64-row tiles at the
+// plain kernel's 4 workgroups per CU up to 256 input channels; one workgroup per CU fewer cost a whole round on the 14x14 layers)
+template <int BM, int BN, int KC>
+__global__ __launch_bounds__(256, BM == 64 ? (KC <= 256 ? 4 : 3) : 2) void igemm_nt_glds_inbn_kernel(IGemmArgs a) {
+    nt_glds_body<BM, BN, 3, false, 1, 1, KC>(a, blockIdx.x, gridDim.x);
 }
 
 template <int BM, int BN, int NST, int LIN, int KG>
@@ -1035,21 +1041,14 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
     // operand-path batch norm: piece i of this thread (LDS row 64 i + 16 wave + (lane >> 2), position lane & 3) holds the
     // global chunk (lane & 3) ^ G((lane >> 4) & 3) of its row -- the same for every i -- i.e. channels 32 cc + 8 gch .. + 7
     const int gch = (lane & 3) ^ lds_swz4(lane >> 4);
+    auto piece_ptr = [&](int buf, int i) { return reinterpret_cast<bf16x8*>(smem + buf * AHB + wave * 1024 + i * 4096 + lane * 16); };
     auto transform_piece = [&](int buf, int i, const f32x4 (&cf)[6]) {
-        bf16x8* ptr = reinterpret_cast<bf16x8*>(smem + buf * AHB + wave * 1024 + i * 4096 + lane * 16);
+        bf16x8* ptr = piece_ptr(buf, i);
         *ptr = bn_act8(*ptr, cf[0], cf[1], cf[2], cf[3], cf[4], cf[5], a.in_act);
     };
-    auto load_coef = [&](int cc, f32x4 (&cf)[6]) {
-        const float* t = inbn_tab + cc * BK + gch * 8;
-        cf[0] = *reinterpret_cast<const f32x4*>(t);
-        cf[1] = *reinterpret_cast<const f32x4*>(t + 4);
-        cf[2] = *reinterpret_cast<const f32x4*>(t + INBN_KMAX);
-        cf[3] = *reinterpret_cast<const f32x4*>(t + INBN_KMAX + 4);
-        cf[4] = *reinterpret_cast<const f32x4*>(t + 2 * INBN_KMAX);
-        cf[5] = *reinterpret_cast<const f32x4*>(t + 2 * INBN_KMAX + 4);
-    };
+    auto load_coef = [&](int cc, f32x4 (&cf)[6]) { inbn_coef<INBN_KMAX>(inbn_tab, cc * BK + gch * 8, cf); };
     if constexpr (INBN) {
-        inbn_load_table(inbn_tab, a, Cin, tid);
+        inbn_load_table<INBN_KMAX>(inbn_tab, a, Cin, tid);
         __syncthreads();
     }
     // prologue: halo of chunk 0, filter tiles of steps 0 and 1 (taps 0 and 1 of chunk 0)
@@ -1101,21 +1100,38 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j].load(reinterpret_cast<const T*>(bst + boff[j]));
+            // INBN: the next chunk's halo tile (issued at tap 0 of this chunk; from tap 2 on this thread's vmcnt wait has
+            // covered it) is transformed one piece per tap, in the buffer nobody reads before the next chunk's tap 0.  The
+            // piece is read WITH the fragments (one LDS latency for all of them), its ~36 VALU instructions are dealt into the
+            // gaps of this step's MFMAs (an MFMA holds the SIMD's issue for 8 of its 16 cycles: two or three plain VALU fit
+            // behind each) and it is written back behind them.  No wait for that write here: the next step's fragment reads
+            // retire it (LDS operations complete in order) long before the barrier in front of the first read of this buffer.
+            const bool XF = INBN && tap >= 2 && tap < 2 + ACNT;        // (the tap loop is fully unrolled: a constant per copy)
+            const bool xf_live = XF && cc + 1 < nch;
+            bf16x8 piece = {};
+            if constexpr (INBN) {
+                if (XF && tap == 2 && xf_live) load_coef(cc + 1, cfn);
+                if (XF && xf_live) piece = *piece_ptr((cc + 1) & 1, tap - 2);
+            }
             __builtin_amdgcn_sched_barrier(0);                  // every fragment read in flight before the first MFMA
 #pragma unroll
             for (int i = 0; i < TM; ++i)
                 if (!((vmask[i] >> tap) & 1u)) af[i] = Frag<T>{};       // padding / beyond the image: this lane's row contributes zero
+            if constexpr (INBN) {
+                if (XF) piece = bn_act8(piece, cfn[0], cfn[1], cfn[2], cfn[3], cfn[4], cfn[5], a.in_act);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) mma16(acc[i][j], af[i], bf[j]);
             if constexpr (INBN) {
-                // next chunk's halo tile (issued at tap 0 of this chunk; from tap 2 on this thread's vmcnt wait has covered it):
-                // one piece per tap, under this step's MFMAs, in the buffer that is read from the next chunk's tap 0 on
-                if (tap >= 2 && tap < 2 + ACNT && cc + 1 < nch) {
-                    if (tap == 2) load_coef(cc + 1, cfn);
-                    transform_piece((cc + 1) & 1, tap - 2, cfn);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the rewritten piece is in LDS before this wave's next barrier
+                if (XF) {
+#pragma unroll
+                    for (int q = 0; q < TM * TN; ++q) {         // 1 MFMA, then up to 3 VALU, ...: the transform rides in the MFMA shadow
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, (40 + TM * TN - 1) / (TM * TN), 0);
+                    }
+                    if (xf_live) *piece_ptr((cc + 1) & 1, tap - 2) = piece;
                 }
             }
             // The tap loop is unrolled, so without this the scheduler sinks the MFMAs of a step -- and with them the
@@ -2024,9 +2040,16 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
             else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, true>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, true>), grid, dim3(256), 0, st, a);
         } else {
-            if (bm == 128) hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<128, 128>), grid, dim3(256), 0, st, a);
-            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<64, 128>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<64, 64>), grid, dim3(256), 0, st, a);
+#define CAPMI_INBN_LAUNCH(BM_, BN_)                                                                                              \
+            do {                                                                                                                 \
+                if (a.K <= 128) hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<BM_, BN_, 128>), grid, dim3(256), 0, st, a);       \
+                else if (a.K <= 256) hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<BM_, BN_, 256>), grid, dim3(256), 0, st, a);  \
+                else hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<BM_, BN_, INBN_KMAX>), grid, dim3(256), 0, st, a);            \
+            } while (0)
+            if (bm == 128) CAPMI_INBN_LAUNCH(128, 128);
+            else if (bn == 128) CAPMI_INBN_LAUNCH(64, 128);
+            else CAPMI_INBN_LAUNCH(64, 64);
+#undef CAPMI_INBN_LAUNCH
         }
         CAPMI_LAUNCH_CHECK("capmi_igemm_nt_bnact");
         return 0;

@@ -146,6 +146,15 @@ class EncoderRunner:
             if isinstance(op, arch.ConvBN):
                 h, w, c = self.shape[op.dst]
                 ws = max(ws, lib().capmi_bn_bwd_ws_floats(B * h * w, c, dtype_code))
+        # capmi_bn_bwd_reduce_spread: eight accumulator rows [8][2C] per batch-norm layer, one buffer for all of them (zeroed by
+        # ONE fill per step, model._compile_train); CAPMI_BN_SPREAD=0 keeps the two-stage reduction
+        self.bn_spread = need_backward and os.environ.get('CAPMI_BN_SPREAD', '1') != '0'
+        self.bn_acc, off = {}, 0
+        for op in enc.ops:
+            if isinstance(op, arch.ConvBN) and id(op) not in self.skipped:
+                self.bn_acc[op.dst] = off
+                off += 16 * self.shape[op.dst][2]
+        self.bn_acc_all = z((max(off, 4),), torch.float32) if self.bn_spread else None
         self.bwd_ws = z((ws,), torch.float32) if need_backward else None  # partial sums of bn_bwd_reduce (scratch)
         self.bwd_ws_side = z((ws,), torch.float32) if need_backward else None
         # partial sums written by data-gradient epilogues (capmi_igemm_nt_bnred): <= one part per 64 rows (+ class tails)
@@ -167,7 +176,11 @@ class EncoderRunner:
         # activated tensor (weight-gradient operand, ReLU mask): it is written on the side lane, under the decoder.
         self.inbn = {}                   # id(consumer op) -> producer op
         self.inbn_tensors = set()        # tensors whose main-lane bn_apply is gone
-        if dtype_code == 1 and os.environ.get('CAPMI_INBN', '1') != '0':
+        # CAPMI_INBN: 0 = off; 1 (default) = 1x1 consumers (the LDS-DMA kernel transforms its A fragments: one VALU pass per staged
+        # element); 2 = 3x3 consumers on the halo-staged kernel as well (the halo tile is transformed in LDS: 1.9-2.8x the
+        # elements of the output tile and no MFMA shadow to hide in -- measured slower, DESIGN.md lesson 39)
+        inbn_level = int(os.environ.get('CAPMI_INBN', '1'))
+        if dtype_code == 1 and inbn_level > 0:
             for op in enc.ops:
                 if not isinstance(op, arch.ConvBN) or id(op) in self.skipped or op.groups != 1 or op.src == 0:
                     continue
@@ -176,7 +189,8 @@ class EncoderRunner:
                     continue
                 if op.src == self.out_id:
                     continue
-                if lib().capmi_igemm_nt_bnact_supported(self._conv_geom(op), op.cout, dtype_code) > 0:
+                kind = lib().capmi_igemm_nt_bnact_supported(self._conv_geom(op), op.cout, dtype_code)
+                if kind == 2 or (kind == 1 and inbn_level >= 2):
                     self.inbn[id(op)] = P
                     self.inbn_tensors.add(P.dst)
 
@@ -496,7 +510,13 @@ class EncoderRunner:
                     assert act == NONE
                     plan.add('capmi_bn_bwd_reduce_final', _p(self.red_ws[slot]), parts, c, _p(red))
                     ws_busy[slot] = None
+                    spread = None
+                elif self.bn_spread:
+                    spread = self.bn_acc_all.data_ptr() + 4 * self.bn_acc[op.dst]
+                    plan.add('capmi_bn_bwd_reduce_spread', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
+                             _p(self.bwd_ws_side if ln else self.bwd_ws), _p(red), spread, M, c, act, code, lane=ln)
                 else:
+                    spread = None
                     plan.add('capmi_bn_bwd_reduce', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']), _p(self.bwd_ws_side if ln else self.bwd_ws), _p(red), M, c, act, code, lane=ln)
                 dres, dres_acc = None, 0
                 if fa is not None and fa.a in shortcut_done:
@@ -511,8 +531,12 @@ class EncoderRunner:
                         dres = self.grad[fa.a]
                         dres_acc = 1 if fa.a in written else 0
                         written.add(fa.a)
-                plan.add('capmi_bn_bwd_apply', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
-                         _p(st.view(op.name + '_bn_scale')), _p(red), _p(draw), 0, _p(dres), dres_acc, M, c, act, code, lane=ln)
+                if spread is not None:
+                    plan.add('capmi_bn_bwd_apply_spread', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
+                             _p(st.view(op.name + '_bn_scale')), _p(red), spread, _p(draw), 0, _p(dres), dres_acc, M, c, act, code, lane=ln)
+                else:
+                    plan.add('capmi_bn_bwd_apply', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
+                             _p(st.view(op.name + '_bn_scale')), _p(red), _p(draw), 0, _p(dres), dres_acc, M, c, act, code, lane=ln)
                 if wl and not ln:
                     plan.record(('dz', op.name), 0)
                     plan.wait(('dz', op.name), 1)

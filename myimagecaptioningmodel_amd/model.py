@@ -181,13 +181,20 @@ class CaptionEngine:
         if zero_in_fwd:
             head = Plan()
             head.add('capmi_fill_f32', _p(self.store.grad), 0.0, self.store.size, lane=1)
+            if enc.bn_acc_all is not None:          # accumulator rows of capmi_bn_bwd_reduce_spread
+                head.add('capmi_fill_f32', _p(enc.bn_acc_all), 0.0, enc.bn_acc_all.numel(), lane=1)
+            head.record(('zero', 'gradient buffers'), 1)
             head.extend(fwd_enc)
             fwd_enc = head
         dec.plan_forward(fwd_dec, enc.out_tensor(), self.W)
         fwd.extend(fwd_enc)
         fwd.extend(fwd_dec)
+        if zero_in_fwd:     # one launch table for the whole step (dp._fuse_step): the first gradient write follows the side lane's fills
+            bwd.wait(('zero', 'gradient buffers'), 0)      # (dropped when forward and backward are launched as two tables: those end joined)
         if not zero_in_fwd:
             bwd.add('capmi_fill_f32', _p(self.store.grad), 0.0, self.store.size)
+            if enc.bn_acc_all is not None:
+                bwd.add('capmi_fill_f32', _p(enc.bn_acc_all), 0.0, enc.bn_acc_all.numel())
         dec.plan_backward(bwd, enc.out_tensor(), enc.out_grad(), self.W, self.WT)
         marks = []
         n_dec = len(bwd)

@@ -419,6 +419,37 @@ def test_batch_norm_chain(dtype, act, res):
     check(host(DX), _nhwc(dx), dtype, name='bn dx')
     if res:
         check(host(DR), _nhwc(dz), dtype, name='d residual')
+    # the form without the second-stage launch: block totals added into eight accumulator rows, summed in the apply prologue
+    acc8 = torch.zeros(16 * C, dtype=f32, device=DEV)
+    red2 = torch.zeros(2 * C, dtype=f32, device=DEV)
+    DX2 = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+    DR2 = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV) if res else None
+    _KEEP.extend([acc8, red2, DX2, DR2])
+    _lib.call('capmi_bn_bwd_reduce_spread', p(DY), p(X), p(Yexact), p(mean), p(invstd), p(bws), p(red2), p(acc8), M, C, ac, code[dtype], stream())
+    _lib.call('capmi_bn_bwd_apply_spread', p(DY), p(X), p(Yexact), p(mean), p(invstd), p(SC), p(red2), p(acc8), p(DX2), 0, p(DR2), 0, M, C, ac,
+              code[dtype], stream())
+    torch.cuda.synchronize()
+    sc_ = float(np.abs(dz).sum((0, 2, 3)).max())
+    assert torch.allclose(red2, red, rtol=1e-5, atol=1e-5 * sc_), float((red2 - red).abs().max())       # same partial sums, another f32 order
+    assert torch.allclose(acc8.view(8, 2 * C).sum(0), red, rtol=1e-5, atol=1e-5 * sc_)
+    check(host(DX2), _nhwc(dx), dtype, name='bn dx (spread)')
+    assert float((DX2.float() - DX.float()).abs().max()) <= (1e-4 if dtype == 'f32' else 2 ** -6) * max(1.0, float(DX.float().abs().max()))
+    if res:
+        assert torch.equal(DR2, DR)
+    # deterministic mode: the pair IS the two-stage form (bit for bit) and leaves the accumulator rows alone
+    prev = _lib.set_deterministic(True)
+    try:
+        acc8.zero_()
+        red3 = torch.zeros(2 * C, dtype=f32, device=DEV)
+        DX3 = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+        _KEEP.extend([red3, DX3])
+        _lib.call('capmi_bn_bwd_reduce_spread', p(DY), p(X), p(Yexact), p(mean), p(invstd), p(bws), p(red3), p(acc8), M, C, ac, code[dtype], stream())
+        _lib.call('capmi_bn_bwd_apply_spread', p(DY), p(X), p(Yexact), p(mean), p(invstd), p(SC), p(red3), p(acc8), p(DX3), 0, None, 0, M, C, ac,
+                  code[dtype], stream())
+        torch.cuda.synchronize()
+        assert torch.equal(red3, red) and torch.equal(DX3, DX) and not bool(acc8.any())
+    finally:
+        _lib.set_deterministic(prev)
 
 
 def test_batch_norm_statistics_no_cancellation():
