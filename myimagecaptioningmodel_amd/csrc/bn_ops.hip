@@ -518,11 +518,12 @@ extern "C" int capmi_bn_apply(const void* x, const float* saved_mean, const floa
 // ACT is a template parameter and the loads of U rows are issued as one batch before any arithmetic: with a run-time
 // activation switch the loop compiled to a branch per element and 2-3 loads in flight per thread -- 2.8 TB/s on
 // cold tensors in the model (5.7 alone on MALL-warm ones), the largest kernel family on the main lane.
-// SPREAD: no second stage.  The block totals go out as f32 atomics into EIGHT accumulator rows acc8[8][2C] (row = workgroup
-// index mod 8: at most a sixteenth of the grid adds to any one address, and a wave instruction covers 256 contiguous
-// bytes -- the memory-side atomic units' full rate, MI355X_MICROARCH.md); bn_bwd_apply sums the eight rows in its prologue.
+// SPREAD: no second stage.  The block totals go out as f32 atomics into BN_SPREAD_ROWS accumulator rows acc[rows][2C] (row =
+// workgroup index mod rows: a quarter of the grid adds to any one address, and a wave instruction covers 256 contiguous
+// bytes -- the memory-side atomic units' full rate, MI355X_MICROARCH.md); bn_bwd_apply sums the rows in its prologue.
 // The dependent ~9 us second-stage launch behind every one of the ~50 reductions of a step is gone; the price is the
 // summation order of a row (not fixed): capmi_deterministic() keeps the two-stage form.
+constexpr int BN_SPREAD_ROWS = 4;       // (capmi.h documents room for 8)
 template <typename T, int ACT, bool SPREAD = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, float* ws,
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             for (int v = 0; v < VEC; ++v) tot[cc * VEC + v] = a1[v];
         }
         __syncthreads();
-        float* row = ws + (int64_t)(blockIdx.x & 7) * 2 * C + (int64_t)blockIdx.y * ncol;
+        float* row = ws + (int64_t)(blockIdx.x & (BN_SPREAD_ROWS - 1)) * 2 * C + (int64_t)blockIdx.y * ncol;
         for (int i = tid; i < ncol; i += 256)
             if (blockIdx.y * ncol + i < C) __hip_atomic_fetch_add(row + i, tot[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
@@ -731,13 +732,15 @@ extern "C" int capmi_bn_bwd_reduce_spread(const void* dy, const void* x, const v
 // singleton attention) makes dz - mean(dz) cancel almost completely.
 // ACT: compile-time activation of the layer's output (none / relu / relu6); DRES: 0 = no residual gradient, 1 = store
 // dz, 2 = accumulate dz; DXACC: dx accumulates.  Batched loads as in bn_bwd_reduce_kernel.
-// acc8 != NULL (capmi_bn_bwd_apply_spread): the sums are the eight accumulator rows of capmi_bn_bwd_reduce_spread, added up
-// here in row order; the first row block also adds them to `red` (one writer per channel).
-template <typename T, int ACT, int DRES, bool DXACC>
+// SPREAD (capmi_bn_bwd_apply_spread): the sums are the BN_SPREAD_ROWS accumulator rows of capmi_bn_bwd_reduce_spread.  Their
+// loads are issued next to the first batch of row loads and added up (in row order) only behind it, like the other
+// per-channel constants: a prologue that waited for them first cost every workgroup one more memory round trip (+4 us per
+// launch, measured).  The first row block also adds the sums to `red` (one writer per channel).
+template <typename T, int ACT, int DRES, bool DXACC, bool SPREAD = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ scale, float* red, const float* __restrict__ acc8, T* dx,
-                                                           T* dres, int M, int C, float inv_m, ColLayout L) {
+                                                           const float* __restrict__ scale, const float* __restrict__ red, const float* __restrict__ acc,
+                                                           float* red_out, T* dx, T* dres, int M, int C, float inv_m, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
     constexpr int U = (ACT ? 1 : 0) + (DRES == 2 ? 1 : 0) + (DXACC ? 1 : 0) >= 2 ? 2 : 4;      // register budget
     const int cc = threadIdx.x % L.cpc, rr = threadIdx.x / L.cpc;
@@ -747,42 +750,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     // formed here, the row loads would wait one memory latency for them at the start of every workgroup
     float k1[VEC], c2[VEC], m0[VEC], mu[VEC];
     float is_[VEC], sc_[VEC], r0_[VEC], r1_[VEC];
+    f32x4 t0[SPREAD ? BN_SPREAD_ROWS : 1][VEC / 4], t1[SPREAD ? BN_SPREAD_ROWS : 1][VEC / 4];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         const int c = chunk * VEC + v;
         is_[v] = invstd[c];
         sc_[v] = scale[c];
         mu[v] = mean[c];
-        if (!acc8) {
+        if constexpr (!SPREAD) {
             r0_[v] = red[c];
             r1_[v] = red[C + c];
         }
     }
-    if (acc8) {         // 2 x 8 rows x VEC floats as 16-byte loads, all in flight together
-        f32x4 t0[8][VEC / 4], t1[8][VEC / 4];
+    if constexpr (SPREAD) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < BN_SPREAD_ROWS; ++j)
 #pragma unroll
             for (int q = 0; q < VEC / 4; ++q) {
-                t0[j][q] = *reinterpret_cast<const f32x4*>(acc8 + (int64_t)j * 2 * C + chunk * VEC + 4 * q);
-                t1[j][q] = *reinterpret_cast<const f32x4*>(acc8 + (int64_t)j * 2 * C + C + chunk * VEC + 4 * q);
+                t0[j][q] = *reinterpret_cast<const f32x4*>(acc + (int64_t)j * 2 * C + chunk * VEC + 4 * q);
+                t1[j][q] = *reinterpret_cast<const f32x4*>(acc + (int64_t)j * 2 * C + C + chunk * VEC + 4 * q);
             }
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { s0 += t0[j][v / 4][v % 4]; s1 += t1[j][v / 4][v % 4]; }
-            r0_[v] = s0;
-            r1_[v] = s1;
-        }
-        if (blockIdx.x == 0 && rr == 0) {
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const int c = chunk * VEC + v;
-                red[c] += r0_[v];
-                red[C + c] += r1_[v];
-            }
-        }
     }
     const int m_begin = blockIdx.x * L.rows_per_block;
     const int m_end = min(M, m_begin + L.rows_per_block);
@@ -818,6 +805,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     };
     const bool first = m + (U - 1) * L.rp < m_end;
     if (first) load(off);
+    if constexpr (SPREAD) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < BN_SPREAD_ROWS; ++j) { s0 += t0[j][v / 4][v % 4]; s1 += t1[j][v / 4][v % 4]; }
+            r0_[v] = s0;
+            r1_[v] = s1;
+        }
+        if (blockIdx.x == 0 && rr == 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                const int c = chunk * VEC + v;
+                red_out[c] += r0_[v];
+                red_out[C + c] += r1_[v];
+            }
+        }
+    }
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
         k1[v] = sc_[v] * is_[v];
@@ -846,9 +851,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 
 template <typename T, int ACT, int DRES>
 static void bn_bwd_apply_launch2(bool dxacc, dim3 grid, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean, const float* invstd,
-                                 const float* scale, float* red, const float* acc8, T* dx, T* dres, int M, int C, const ColLayout& L) {
-    if (dxacc) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, true>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, 1.f / (float)M, L);
-    else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, false>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, acc8, dx, dres, M, C, 1.f / (float)M, L);
+                                 const float* scale, float* red, const float* acc, T* dx, T* dres, int M, int C, const ColLayout& L) {
+    const float inv_m = 1.f / (float)M;
+    if (acc) {
+        if (dxacc) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, true, true>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, nullptr, acc, red, dx, dres, M, C, inv_m, L);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, false, true>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, nullptr, acc, red, dx, dres, M, C, inv_m, L);
+    } else {
+        if (dxacc) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, true, false>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, nullptr, nullptr, dx, dres, M, C, inv_m, L);
+        else hipLaunchKernelGGL((bn_bwd_apply_kernel<T, ACT, DRES, false, false>), grid, dim3(256), 0, st, dy, x, y, mean, invstd, scale, red, nullptr, nullptr, dx, dres, M, C, inv_m, L);
+    }
 }
 template <typename T, int ACT>
 static void bn_bwd_apply_launch1(int dres_mode, bool dxacc, dim3 grid, hipStream_t st, const T* dy, const T* x, const T* y, const float* mean,

@@ -176,10 +176,13 @@ class EncoderRunner:
         # activated tensor (weight-gradient operand, ReLU mask): it is written on the side lane, under the decoder.
         self.inbn = {}                   # id(consumer op) -> producer op
         self.inbn_tensors = set()        # tensors whose main-lane bn_apply is gone
-        # CAPMI_INBN: 0 = off; 1 (default) = 1x1 consumers (the LDS-DMA kernel transforms its A fragments: one VALU pass per staged
-        # element); 2 = 3x3 consumers on the halo-staged kernel as well (the halo tile is transformed in LDS: 1.9-2.8x the
-        # elements of the output tile and no MFMA shadow to hide in -- measured slower, DESIGN.md lesson 39)
-        inbn_level = int(os.environ.get('CAPMI_INBN', '1'))
+        # CAPMI_INBN: 0 (default) = off; 1 = 1x1 consumers (the LDS-DMA kernel transforms its A fragments: one VALU pass per
+        # staged element); 2 = 3x3 consumers on the halo-staged kernel as well (the halo tile is transformed in LDS: 1.9-2.8x
+        # the elements of the output tile, in a loop with no MFMA shadow to hide ~50 VALU instructions per piece in).
+        # Measured on the bench workload, A/B on one box (DESIGN.md lesson 39, profiles/r03_inbn_ab.txt): level 1 9.08 ms per
+        # step against 9.06 without, level 2 9.26 -- bit-identical results, no gain: the bn_apply launches it takes off the
+        # forward chain (0.19 ms) come back as slower convolutions.  Kept as a tested alternate, off by default.
+        inbn_level = int(os.environ.get('CAPMI_INBN', '0'))
         if dtype_code == 1 and inbn_level > 0:
             for op in enc.ops:
                 if not isinstance(op, arch.ConvBN) or id(op) in self.skipped or op.groups != 1 or op.src == 0:

@@ -313,11 +313,12 @@ def test_plan_runner_equals_the_per_launch_host_walk(encoder, dtype, monkeypatch
 
 # ------------------------------------------------------------------ persistent LSTM recurrence inside the engine
 @pytest.mark.parametrize('layers', [1, 2])
-def test_engine_with_persistent_recurrence_equals_per_step_plan(layers, monkeypatch):
+def test_engine_with_persistent_recurrence_equals_per_step_plan(layers, monkeypatch, deterministic):
     """H = 256, B = 16 bf16: the train step whose LSTM layers each run as ONE forward and ONE backward launch
     (capmi_lstm_seq_*, grid barriers) against the same step with per-step launches (CAPMI_LSTM_SEQ=0, fused backward
     steps CAPMI_LSTM_FUSE=2 -- the arithmetic the persistent kernels mirror): forward bit-identical, gradients equal up
-    to f32 atomic order; and against the oracle within the bf16 bounds of test_gpu_model."""
+    to the FMA contraction in the cell (deterministic mode: no atomic-order noise on top); and against the oracle within the
+    bf16 bounds of test_gpu_model."""
     ocfg, ecfg = _cfgs('mobilenetv2', 'slots', 'bf16', S=64, H=256, E=64, V=120, L=7)
     ocfg['rnn_layer'] = ecfg['rnn_layer'] = layers
     B = 16
@@ -348,3 +349,36 @@ def test_engine_with_persistent_recurrence_equals_per_step_plan(layers, monkeypa
     for name in ('lstm_w', 'lstm_b', 'word_embedding', 'fc_7.w_0') + (('lstm_w_l1',) if layers == 2 else ()):
         x, y = a['grads'][name].ravel(), grads_o[name].ravel()
         assert float(x @ y / (np.linalg.norm(x) * np.linalg.norm(y) + 1e-30)) >= 0.97, name
+
+
+# ------------------------------------------------------------------ batch norm in the consumer's operand path, inside the engine
+@pytest.mark.parametrize('level', [1, 2])
+def test_operand_path_batch_norm_in_the_engine_is_bit_identical(level, monkeypatch, deterministic):
+    """CAPMI_INBN=1 / 2 (capmi_igemm_nt_bnact on the 1x1 / also the halo-staged 3x3 consumers, the producers' bn_apply moved
+    to the side lane) against the default plan: the same bits everywhere -- loss, logits, every conv output and activated
+    tensor after the step, every gradient (deterministic mode) -- on a ResNet-50 whose res2 / res3 layers are large enough
+    for both kernel families (MobileNetV2.py:88-121: the unit chain this fuses)."""
+    ocfg, ecfg = _cfgs('resnet50', 'slots', 'bf16', S=128)
+    B = 8
+    params, image, caption = _data(ocfg, B, seed=4)
+    out = {}
+    for mode in (0, level):
+        monkeypatch.setenv('CAPMI_INBN', str(mode))
+        eng = _engine(ecfg, params)
+        loss = float(eng.forward_backward(image, caption).cpu()[0])
+        torch.cuda.synchronize()
+        prog = eng._train[B]
+        enc = prog['enc']
+        out[mode] = dict(loss=loss, logits=prog['dec'].logits.clone(), raw={k: v.clone() for k, v in enc.raw.items()},
+                         act={k: v.clone() for k, v in enc.act.items()}, grads=eng.export_reference_grads(), n_fused=len(enc.inbn),
+                         calls=[c[1] for c in prog['fwd'].calls if c[0] is not None])
+    a, b = out[0], out[level]
+    assert a['n_fused'] == 0 and b['n_fused'] >= (10 if level == 1 else 16), b['n_fused']
+    assert b['calls'].count('capmi_igemm_nt_bnact') == b['n_fused'] and a['calls'].count('capmi_igemm_nt_bnact') == 0
+    assert a['loss'] == b['loss'] and torch.equal(a['logits'], b['logits'])
+    for k in a['raw']:
+        assert torch.equal(a['raw'][k], b['raw'][k]), ('conv output', k)
+    for k in a['act']:
+        assert torch.equal(a['act'][k], b['act'][k]), ('activated tensor', k)
+    for n, g in a['grads'].items():
+        np.testing.assert_array_equal(b['grads'][n], g, err_msg=n)
