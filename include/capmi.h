@@ -109,15 +109,18 @@ int capmi_igemm_nt_bnact(const void* x_raw, const void* w, void* y, const capmi_
                          float* stats, int dtype, void* stream);
 
 /* Several independent capmi_igemm_nt products with disjoint outputs (the output-parity classes of a
- * strided convolution's data gradient: small GEMMs that under-fill the chip one at a time), issued
- * together.  Semantics = the calls one after another (bias, statistics, act off, output in `dtype`);
- * eligible groups (bf16, N > 64) run as ONE launch, anything else falls back to per-call launches. */
+ * strided convolution's data gradient; the p_hid / sent_emb projections of a decode step,
+ * model_adaAttention_aic.py:99,104: small GEMMs that under-fill the chip one at a time), issued
+ * together.  Semantics = the calls one after another (statistics off, output in `dtype`; bias may be NULL, act
+ * CAPMI_ACT_NONE); eligible groups (bf16, every call on the same LDS-DMA tile shape) run as ONE launch, anything else
+ * falls back to per-call launches. */
 typedef struct capmi_igemm_nt_call {
     const void* x; const void* w; void* y;
     capmi_conv_geom g;
     int N, ldw, ldy;
     const void* addend; int ld_addend;
     const void* ysaved; int ld_saved; int dact;
+    const float* bias; int act;
 } capmi_igemm_nt_call;
 int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count, int dtype, void* stream);
 
@@ -363,6 +366,21 @@ int capmi_softmax_xent_bwd(const float* logits, const int64_t* target, const flo
                            int padding_idx, int dtype, void* stream);
 /* layers.argmax (:120): lowest index on ties; ids_out int64 [M], also f32 copy (quirk Q2). */
 int capmi_argmax(const float* logits, int64_t* ids_out, float* ids_f32, int ld_f32, int M, int V, int ld, void* stream);
+
+/* One decode step's state plumbing in two launches instead of five (eval branches of Decoder.call,
+ * model_adaAttention_aic.py:84-92 under :119-123; beam search: this build's extension).
+ * capmi_decode_prep: row r of xh [R][ldx] (= [embedding | global feature | h_prev]) gets the embedding of ids[r] in columns
+ *   0..E-1 (zero row for padding_idx / out-of-range ids, :28-32) and h_src[rows ? rows[r] : r] in columns h_col..h_col+H-1
+ *   -- the survivors' hidden state of a beam step, or the previous step's own (rows NULL).  The columns in between (the
+ *   global image feature, :86) are written once before the loop and left alone.  With the LSTM's and the sentinel gate's
+ *   weights stacked [4H + H][E + 2H], ONE capmi_igemm_nt on xh then gives the lstm_unit's gate pre-activations and the
+ *   sentinel gate's (:87-91: fc over the concatenated input, exactly as the reference's lstm_unit concatenates).
+ * capmi_lstm_cell_sentinel_fwd: gs [R][ld_gs] = [i | f | o | g | sentinel gate] pre-activations; c_prev = c_src[rows ?
+ *   rows[r] : r]; writes c, h (lstm_unit, forget_bias 0, :87-88) and s = sigmoid(sentinel gate) * tanh(c) (:91-92). */
+int capmi_decode_prep(const int64_t* ids, const void* table, const void* h_src, const int* rows, void* xh, int R, int E, int H,
+                      int V, int ldx, int h_col, int padding_idx, int dtype, void* stream);
+int capmi_lstm_cell_sentinel_fwd(const void* gs, int ld_gs, const void* c_src, const int* rows, void* h, void* c, void* s,
+                                 int R, int H, int dtype, void* stream);
 
 /* Beam-search decode (BUILD-DEFINED extension of the eval graph, BASELINE cfg 5; infer.py only has the greedy loop).
  * Rows are beam-major: row k*B + b holds hypothesis k of image b.  One step: capmi_beam_step takes the f32 logits

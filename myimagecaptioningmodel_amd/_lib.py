@@ -25,7 +25,8 @@ class NtCall(ctypes.Structure):
     _fields_ = [('x', ctypes.c_void_p), ('w', ctypes.c_void_p), ('y', ctypes.c_void_p), ('g', ConvGeom),
                 ('N', ctypes.c_int), ('ldw', ctypes.c_int), ('ldy', ctypes.c_int),
                 ('addend', ctypes.c_void_p), ('ld_addend', ctypes.c_int),
-                ('ysaved', ctypes.c_void_p), ('ld_saved', ctypes.c_int), ('dact', ctypes.c_int)]
+                ('ysaved', ctypes.c_void_p), ('ld_saved', ctypes.c_int), ('dact', ctypes.c_int),
+                ('bias', ctypes.c_void_p), ('act', ctypes.c_int)]
 
 
 def gemm_geom(rows, K, ldx=None):
@@ -73,6 +74,8 @@ SIGNATURES = {
     'capmi_bcast_rows': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'capmi_bcast_rows_bwd': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'capmi_lstm_cell_fwd': [_p, _p, _p, _p, _i, _i, _i, _p],
+    'capmi_decode_prep': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_lstm_cell_sentinel_fwd': [_p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p],
     'capmi_lstm_cell_bwd': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_lstm_step_fwd': [_p, _p, _i, _p, _p, _p, _p, _i, _i, _i, _p],
     'capmi_lstm_step_bwd': [_p, _p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],

@@ -149,6 +149,80 @@ extern "C" int capmi_lstm_cell_fwd(const void* gates, const void* c_prev, void* 
     CAPMI_LAUNCH_CHECK("capmi_lstm_cell_fwd");
     return 0;
 }
+// ------------------------------------------------------------------ decode step: state plumbing (capmi.h)
+template <typename T>
+__global__ __launch_bounds__(256) void decode_prep_kernel(const int64_t* __restrict__ ids, const T* __restrict__ table, const T* __restrict__ h_src,
+                                                          const int* __restrict__ rows, T* xh, int R, int ecpr, int hcpr, int V, int ldx, int h_col,
+                                                          int padding_idx) {
+    constexpr int VEC = Vec<T>::N;
+    const int per = ecpr + hcpr;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= R * per) return;
+    const int r = e / per, cc = e % per;
+    if (cc < ecpr) {
+        const int64_t id = ids[r];
+        Vec<T> v = (id == padding_idx || id < 0 || id >= V) ? vzero<T>() : vload<T>(table + (id * ecpr + cc) * VEC);
+        vstore<T>(xh + (int64_t)r * ldx + cc * VEC, v);
+    } else {
+        const int hc = cc - ecpr;
+        const int src = rows ? rows[r] : r;
+        vstore<T>(xh + (int64_t)r * ldx + h_col + hc * VEC, vload<T>(h_src + ((int64_t)src * hcpr + hc) * VEC));
+    }
+}
+extern "C" int capmi_decode_prep(const int64_t* ids, const void* table, const void* h_src, const int* rows, void* xh, int R, int E, int H,
+                                 int V, int ldx, int h_col, int padding_idx, int dtype, void* stream) {
+    CAPMI_CHECK(ids && table && h_src && xh, "capmi_decode_prep: null pointer");
+    CAPMI_DISPATCH(dtype, "capmi_decode_prep", {
+        constexpr int VEC = Vec<T>::N;
+        CAPMI_CHECK(E % VEC == 0 && H % VEC == 0 && ldx % VEC == 0 && h_col % VEC == 0 && h_col >= E && h_col + H <= ldx,
+                    "capmi_decode_prep: E=%d H=%d ldx=%d h_col=%d must be multiples of %d with E <= h_col <= ldx - H", E, H, ldx, h_col, VEC);
+        const int ecpr = E / VEC, hcpr = H / VEC;
+        hipLaunchKernelGGL(decode_prep_kernel<T>, dim3(cdiv((int64_t)R * (ecpr + hcpr), 256)), dim3(256), 0, (hipStream_t)stream, ids, (const T*)table,
+                           (const T*)h_src, rows, (T*)xh, R, ecpr, hcpr, V, ldx, h_col, padding_idx);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_decode_prep");
+    return 0;
+}
+// the arithmetic of lstm_cell_fwd_kernel followed by sentinel_fwd_kernel's on the NEW cell state (both round h / c / s to T
+// exactly where the two kernels do: s reads the stored c)
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_cell_sentinel_fwd_kernel(const T* __restrict__ gs, int ld_gs, const T* __restrict__ c_src,
+                                                                     const int* __restrict__ rows, T* h, T* c, T* s, int R, int cpr) {
+    constexpr int VEC = Vec<T>::N;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= R * cpr) return;
+    const int r = e / cpr, cc = e % cpr;
+    const int H = cpr * VEC;
+    const T* gr = gs + (int64_t)r * ld_gs + cc * VEC;
+    Vec<T> gi = vload<T>(gr), gf = vload<T>(gr + H), go = vload<T>(gr + 2 * H), gg = vload<T>(gr + 3 * H), sg = vload<T>(gr + 4 * H);
+    const int src = rows ? rows[r] : r;
+    Vec<T> cp = vload<T>(c_src + ((int64_t)src * cpr + cc) * VEC), hv, cv, sv;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        float i_ = sigmoidf_(gi.get(v)), f_ = sigmoidf_(gf.get(v)), o_ = sigmoidf_(go.get(v)), g_ = tanhf_(gg.get(v));
+        float cn = f_ * cp.get(v) + i_ * g_;
+        cv.set(v, cn);
+        hv.set(v, o_ * tanhf_(cn));
+        sv.set(v, sigmoidf_(sg.get(v)) * tanhf_(cv.get(v)));
+    }
+    vstore<T>(h + (int64_t)e * VEC, hv);
+    vstore<T>(c + (int64_t)e * VEC, cv);
+    vstore<T>(s + (int64_t)e * VEC, sv);
+}
+extern "C" int capmi_lstm_cell_sentinel_fwd(const void* gs, int ld_gs, const void* c_src, const int* rows, void* h, void* c, void* s,
+                                            int R, int H, int dtype, void* stream) {
+    CAPMI_CHECK(gs && c_src && h && c && s, "capmi_lstm_cell_sentinel_fwd: null pointer");
+    CAPMI_CHECK(c_src != c || !rows, "capmi_lstm_cell_sentinel_fwd: a gathered cell state cannot be updated in place");
+    CAPMI_DISPATCH(dtype, "capmi_lstm_cell_sentinel_fwd", {
+        CAPMI_CHECK(H % Vec<T>::N == 0 && ld_gs % Vec<T>::N == 0 && ld_gs >= 5 * H, "capmi_lstm_cell_sentinel_fwd: H / ld_gs not multiples of the vector width (ld_gs >= 5H)");
+        const int cpr = H / Vec<T>::N;
+        hipLaunchKernelGGL(lstm_cell_sentinel_fwd_kernel<T>, dim3(cdiv((int64_t)R * cpr, 256)), dim3(256), 0, (hipStream_t)stream, (const T*)gs, ld_gs,
+                           (const T*)c_src, rows, (T*)h, (T*)c, (T*)s, R, cpr);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_lstm_cell_sentinel_fwd");
+    return 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void lstm_cell_bwd_kernel(const T* __restrict__ gates, const T* __restrict__ c_prev, const T* __restrict__ c,
                                                             const T* __restrict__ dh, const T* __restrict__ dc_in, T* dgates, T* dc_prev,

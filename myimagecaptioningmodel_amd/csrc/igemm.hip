@@ -2166,23 +2166,39 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
     for (int first = 0; first < count; first += NT_GROUP_MAX) {
         const int n = count - first < NT_GROUP_MAX ? count - first : NT_GROUP_MAX;
         NtGroup grp;
-        bool fuse = dtype == CAPMI_BF16 && n > 1, conv1 = true;
-        long long blocks = 0;
+        // one launch when every call lands on the SAME LDS-DMA tile shape: 64 x 128 (4 x 1 waves) or 64 x 64
+        bool fuse128 = dtype == CAPMI_BF16 && n > 1, fuse64 = fuse128, conv1 = true, lin = true;
+        long long blocks128 = 0, blocks64 = 0;
         for (int i = 0; i < n; ++i) {
             const capmi_igemm_nt_call& c = calls[first + i];
-            if (nt_prepare(grp.a[i], c.x, c.w, c.y, &c.g, c.N, c.ldw, c.ldy, nullptr, c.addend, c.ld_addend, c.ysaved, c.ld_saved, nullptr,
-                           0, c.dact, 0, 0, nullptr, dtype)) return 1;
+            if (nt_prepare(grp.a[i], c.x, c.w, c.y, &c.g, c.N, c.ldw, c.ldy, c.bias, c.addend, c.ld_addend, c.ysaved, c.ld_saved, nullptr,
+                           c.act, c.dact, 0, 0, nullptr, dtype)) return 1;
             const IGemmArgs& a = grp.a[i];
-            fuse = fuse && !nt_uses_skinny(&c.g, a.M, a.K, false, dtype) && nt_cfg(a.M, a.N, a.K, dtype).bn == 128 && nt_cfg(a.M, a.N, a.K, dtype).wmw == 4;
+            const bool skinny = nt_uses_skinny(&c.g, a.M, a.K, false, dtype);
+            const NtCfg cfg = nt_cfg(a.M, a.N, a.K, dtype);
+            fuse128 = fuse128 && !skinny && cfg.bn == 128 && cfg.wmw == 4;
+            fuse64 = fuse64 && !skinny && cfg.wmw == 5 && !nt_halo3_ok(a, &c.g, 0);
             conv1 = conv1 && c.g.up == 1 && c.g.Cin >= 32;
-            grp.first[i] = (int)blocks;
-            blocks += ((long long)cdiv(a.M, 64) * cdiv(a.N, 128) + 7) / 8 * 8;      // ranges start at multiples of 8 (XCD order)
+            lin = lin && c.g.kh == 1 && c.g.kw == 1 && c.g.up == 1 && c.g.pad == 0 && (c.g.Ho - 1) * c.g.sd < c.g.Hi && (c.g.Wo - 1) * c.g.sd < c.g.Wi;
+            blocks128 += ((long long)cdiv(a.M, 64) * cdiv(a.N, 128) + 7) / 8 * 8;      // ranges start at multiples of 8 (XCD order)
+            blocks64 += ((long long)cdiv(a.M, 64) * cdiv(a.N, 64) + 7) / 8 * 8;
         }
-        grp.first[n] = (int)blocks;
         grp.count = n;
-        if (fuse && blocks < (1ll << 31)) {
-            if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
-            else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+        const long long blocks = fuse128 ? blocks128 : blocks64;
+        if ((fuse128 || fuse64) && blocks < (1ll << 31)) {
+            long long b = 0;
+            for (int i = 0; i < n; ++i) {
+                grp.first[i] = (int)b;
+                b += ((long long)cdiv(grp.a[i].M, 64) * cdiv(grp.a[i].N, fuse128 ? 128 : 64) + 7) / 8 * 8;
+            }
+            grp.first[n] = (int)b;
+            if (fuse128) {
+                if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            } else {
+                if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            }
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt_group");
         } else {
             for (int i = 0; i < n; ++i) {

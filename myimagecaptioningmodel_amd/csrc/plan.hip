@@ -87,6 +87,8 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_bcast_rows),
     CAPMI_ENTRY(capmi_bcast_rows_bwd),
     CAPMI_ENTRY(capmi_lstm_cell_fwd),
+    CAPMI_ENTRY(capmi_decode_prep),
+    CAPMI_ENTRY(capmi_lstm_cell_sentinel_fwd),
     CAPMI_ENTRY(capmi_lstm_cell_bwd),
     CAPMI_ENTRY(capmi_lstm_step_fwd),
     CAPMI_ENTRY(capmi_lstm_step_bwd),

@@ -21,7 +21,7 @@ import os
 
 import torch
 
-from ._lib import lib, ACT_NONE, ACT_RELU, ACT_TANH, WGRAD_WS_BYTES, gemm_geom, wgrad_workspace
+from ._lib import lib, ACT_NONE, ACT_RELU, ACT_TANH, WGRAD_WS_BYTES, NtCall, gemm_geom, wgrad_workspace
 from .params import FC
 
 
@@ -159,9 +159,11 @@ class DecoderRunner:
         if self.slots:
             self._gemm(plan, _p(self.V0), B * K, H, _p(W(w3)), H, _p(self.Ve), bias=_p(st.view(b3)))              # :53
 
-    def _plan_post_lstm(self, plan, W, rows, X, Hprev, Hcur, Ccur, row0=0):
+    def _plan_post_lstm(self, plan, W, rows, X, Hprev, Hcur, Ccur, row0=0, have_s=False):
         """Everything of one loop body after the lstm_unit (:89-117) for `rows` rows starting at
-        row `row0` of the time-major buffers; X/Hprev/Hcur/Ccur are pre-offset pointers."""
+        row `row0` of the time-major buffers; X/Hprev/Hcur/Ccur are pre-offset pointers.  have_s: the sentinel S is
+        already in place (the fused decode step, capmi_lstm_cell_sentinel_fwd) and the two projections that only need h
+        and S -- p_hid :99 and sent_emb :104 -- go out as ONE grouped launch."""
         st, H, E, V = self.store, self.H, self.E, self.V
         es = self.SGpre.element_size()
         o = row0 * H * es
@@ -175,16 +177,27 @@ class DecoderRunner:
         w10, b10 = self._fc('alpha')
         w11, b11 = self._fc('out')
         w12, b12 = self._fc('proj')
-        self._gemm(plan, X, rows, E + H, _p(W(w5)), H, SG, bias=_p(st.view(b5)))                                  # :89
-        self._gemm(plan, Hprev, rows, H, _p(W(w6)), H, SG, bias=_p(st.view(b6)), addend=SG, ld_add=H)            # :90-91
-        plan.add('capmi_sentinel_fwd', SG, Ccur, S, rows * H, self.code)                                          # :91-92
-        self._gemm(plan, Hcur, rows, H, _p(W(w7)), H, P, bias=_p(st.view(b7)), act=ACT_TANH)                     # :99
+        if not have_s:
+            self._gemm(plan, X, rows, E + H, _p(W(w5)), H, SG, bias=_p(st.view(b5)))                              # :89
+            self._gemm(plan, Hprev, rows, H, _p(W(w6)), H, SG, bias=_p(st.view(b6)), addend=SG, ld_add=H)        # :90-91
+            plan.add('capmi_sentinel_fwd', SG, Ccur, S, rows * H, self.code)                                      # :91-92
         Tn = rows // self.B
         Q = SE = None
         if self.slots:
             Q, SE = _p(self.Q) + o, _p(self.SE) + o
+        if have_s and self.slots:
+            calls = (NtCall * 2)()
+            for cl, (xin, wn_, bn_, out, act) in zip(calls, ((Hcur, w7, b7, P, ACT_TANH), (S, w9, b9, SE, ACT_NONE))):   # :99, :104
+                cl.x, cl.w, cl.y, cl.g = xin, _p(W(wn_)), out, gemm_geom(rows, H)
+                cl.N, cl.ldw, cl.ldy = H, H, H
+                cl.bias, cl.act = _p(st.view(bn_)), act
+            plan.add('capmi_igemm_nt_group', calls, 2, self.code)
             self._gemm(plan, P, rows, H, _p(W(w8)), H, Q, bias=_p(st.view(b8)))                                   # :102
-            self._gemm(plan, S, rows, H, _p(W(w9)), H, SE, bias=_p(st.view(b9)))                                  # :104
+        else:
+            self._gemm(plan, Hcur, rows, H, _p(W(w7)), H, P, bias=_p(st.view(b7)), act=ACT_TANH)                 # :99
+            if self.slots:
+                self._gemm(plan, P, rows, H, _p(W(w8)), H, Q, bias=_p(st.view(b8)))                               # :102
+                self._gemm(plan, S, rows, H, _p(W(w9)), H, SE, bias=_p(st.view(b9)))                              # :104
         alpha = _p(self.alpha) + row0 * (self.K + 1) * 4
         plan.add('capmi_ada_attention_fwd', _p(self.Ve), _p(self.Vt), Q, SE, S, P, _p(W(w10)) if self.slots else None,
                  _p(st.view(b10)), CTXP, alpha, Tn, self.B, self.K, H, self.slots, self.code)                     # :103-113
@@ -366,6 +379,53 @@ class DecoderRunner:
         self._gemm(plan, _p(self.dg), B, H, _p(WT(w1)), C, _p(self.dAmean))
         plan.add('capmi_mean_rows_bwd', _p(self.dAmean), _p(dA), B, K, C, code)
 
+    # ------------------------------------------------------------------ fused decode step (one LSTM layer)
+    fuse_decode = True      # CAPMI_DECODE_FUSE=0: the per-projection step (round 2; the only form for rnn_layer > 1)
+
+    def _decode_fused(self):
+        return self.fuse_decode and self.L == 1 and os.environ.get('CAPMI_DECODE_FUSE', '1') != '0'
+
+    def build_stacked(self, R):
+        """Buffers of the fused decode step: xh = [embedding | global feature | h_prev] rows, gs = [i | f | o | g | sentinel
+        gate] pre-activations, and the stacked weight / bias of the ONE GEMM between them: rows 0..4H-1 = lstm_w (already
+        [in | H] wide, the lstm_unit's fc over the concatenated input, :87-88), rows 4H..5H-1 = [fc_5 | fc_6] (:89-90)."""
+        H, E = self.H, self.E
+        dev = self.X.device
+        self.XH = torch.zeros((R, E + 2 * H), dtype=self.tdt, device=dev)
+        self.GS = torch.zeros((R, 5 * H), dtype=self.tdt, device=dev)
+        self.Wstack = torch.zeros((5 * H, E + 2 * H), dtype=self.tdt, device=dev)
+        self.bstack = torch.zeros((5 * H,), dtype=torch.float32, device=dev)
+        self.stack_version = None
+
+    def refresh_stacked(self, W, version):
+        """Copies the current weights into the stacked GEMM operand (device-to-device slices; called by the engine whenever
+        the weight shadows changed since the last decode)."""
+        if getattr(self, 'Wstack', None) is None or self.stack_version == version:
+            return
+        st, H, E = self.store, self.H, self.E
+        w5, b5 = self._fc('p_word')
+        w6, b6 = self._fc('p_hidden')
+        self.Wstack[:4 * H].copy_(W('lstm_w').reshape(4 * H, E + 2 * H))
+        self.Wstack[4 * H:, :E + H].copy_(W(w5).reshape(H, E + H))
+        self.Wstack[4 * H:, E + H:].copy_(W(w6).reshape(H, H))
+        self.bstack[:4 * H].copy_(st.view('lstm_b').reshape(-1))
+        self.bstack[4 * H:].copy_(st.view(b5).reshape(-1) + st.view(b6).reshape(-1))
+        self.stack_version = version
+
+    def _plan_fused_step(self, plan, W, R, rows, h_src, c_src, h_dst, c_dst):
+        """One decode step in 11 launches (19 before): state plumbing (embedding + the survivors' h into the GEMM operand),
+        ONE GEMM for the lstm_unit's gates and the sentinel gate, cell + sentinel, p_hid || sent_emb grouped, hid_emb,
+        attention, out, proj, vocabulary -- then the caller's argmax / beam step.  rows: device int32 row map of the
+        surviving hypotheses (None: identity)."""
+        H, E = self.H, self.E
+        code = self.code
+        plan.add('capmi_decode_prep', _p(self.ids), _p(W('word_embedding')), h_src, rows, _p(self.XH), R, E, H, self.V, E + 2 * H, E + H,
+                 self.pad, code)                                                                                  # :84-86 (+ beam gather)
+        plan.add('capmi_igemm_nt', _p(self.XH), _p(self.Wstack), _p(self.GS), gemm_geom(R, E + 2 * H), 5 * H, E + 2 * H, 5 * H,
+                 _p(self.bstack), None, 0, None, 0, None, ACT_NONE, ACT_NONE, 0, code)                            # :87-91
+        plan.add('capmi_lstm_cell_sentinel_fwd', _p(self.GS), 5 * H, c_src, rows, h_dst, c_dst, _p(self.S), R, H, code)   # :87-88, :91-92
+        self._plan_post_lstm(plan, W, R, _p(self.XH), None, h_dst, c_dst, have_s=True)
+
     # ------------------------------------------------------------------ greedy decode (eval graph)
     def plan_greedy(self, plan, A, W, out_ids_f32, Ti):
         """`eval_network` :185-189 + the eval branches of Decoder.call: first fed token start_idx
@@ -376,6 +436,16 @@ class DecoderRunner:
         code = self.code
         es = self.X.element_size()
         self._plan_bridge(plan, A, W)
+        if self._decode_fused():
+            self.build_stacked(B)
+            plan.add('capmi_bcast_rows', _p(self.g), _p(self.XH), 1, B, H, E + 2 * H, E, code)
+            for t in range(Ti):
+                cur, nxt = (t % 2), ((t + 1) % 2)
+                hp, cp = _p(self.Hbufs[0]) + cur * B * H * es, _p(self.Cbufs[0]) + cur * B * H * es
+                hn, cn = _p(self.Hbufs[0]) + nxt * B * H * es, _p(self.Cbufs[0]) + nxt * B * H * es
+                self._plan_fused_step(plan, W, B, None, hp, cp, hn, cn)
+                plan.add('capmi_argmax', _p(self.logits), _p(self.ids), _p(out_ids_f32) + t * 4, Ti, B, self.V, self.Vld)  # :120-123
+            return
         plan.add('capmi_bcast_rows', _p(self.g), _p(self.X), 1, B, H, E + H, E, code)
         # per layer two (h, c) row blocks used alternately: block 0 starts as the zero state (:63)
         for t in range(Ti):
@@ -414,6 +484,27 @@ class DecoderRunner:
         self.beam_lse, self.beam_rows = z((R,), torch.float32), z((R,), torch.int32)
         self.beam_parents, self.beam_tokens = z((Ti, beam, B), torch.int32), z((Ti, beam, B), torch.int32)
         self._plan_bridge(plan, A, W)
+        if self._decode_fused():
+            # the step's new (h, c) land in buffer 1 - t % 2 ... the survivors are picked from it by the NEXT step's prep / cell
+            # kernels through beam_rows: no gather launches, two (h, c) buffers used alternately
+            self.build_stacked(R)
+            self.beam_ident = torch.arange(R, dtype=torch.int32, device=dev)
+            plan.add('capmi_bcast_rows', _p(self.g), _p(self.XH), beam, B, H, E + 2 * H, E, code)
+            plan.add('capmi_fill_f32', _p(self.beam_h[0][0]), 0.0, R * H * es // 4)         # h_{-1} = c_{-1} = 0 (:63)
+            plan.add('capmi_fill_f32', _p(self.beam_c[0][0]), 0.0, R * H * es // 4)
+            for t in range(Ti):
+                sin, sout = self.beam_score[t % 2], self.beam_score[(t + 1) % 2]
+                src, dst = t % 2, (t + 1) % 2
+                rows = _p(self.beam_rows) if t > 0 else None                                # step 0: every row starts from the zero state
+                self._plan_fused_step(plan, W, R, rows, _p(self.beam_h[0][src]), _p(self.beam_c[0][src]),
+                                      _p(self.beam_h[0][dst]), _p(self.beam_c[0][dst]))
+                off = t * beam * B * 4
+                plan.add('capmi_beam_step', _p(self.logits), self.V, self.Vld, B, beam, _p(sin), _p(sout), _p(self.beam_cand_val),
+                         _p(self.beam_cand_idx), _p(self.beam_lse), _p(self.beam_parents) + off, _p(self.beam_tokens) + off,
+                         _p(self.ids), _p(self.beam_rows))
+            plan.add('capmi_beam_backtrack', _p(self.beam_tokens), _p(self.beam_parents), _p(out_ids_f32), Ti, B, beam)
+            self.beam_final_score = self.beam_score[Ti % 2]
+            return
         plan.add('capmi_bcast_rows', _p(self.g), _p(self.X), beam, B, H, E + H, E, code)
         for l in range(self.L):
             plan.add('capmi_fill_f32', _p(self.beam_h[l][0]), 0.0, R * H * es // 4)         # h_{-1} = c_{-1} = 0 (:63)

@@ -143,6 +143,7 @@ class CaptionEngine:
     def refresh_shadows(self):
         self.shadow_plan.run(self._stream())
         self.shadows_dirty = False
+        self.shadow_version = getattr(self, 'shadow_version', 0) + 1
 
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -471,6 +472,7 @@ class CaptionEngine:
             raise ValueError('image feed must be %s, got %s' % (tuple(prog['image'].shape), tuple(img.shape)))
         prog['image'].copy_(img)
         dec = prog['dec']
+        dec.refresh_stacked(self.W, (getattr(self, 'shadow_version', 0), self.step_count, id(self.store.flat)))
         dec.ids[:max(1, beam) * B].fill_(self.cfg['start_idx'])                   # :56-58
         if beam > 1 or scored:
             dec.beam_score[0].fill_(-1e30)

@@ -727,6 +727,66 @@ def test_fused_lstm_steps_equal_product_plus_cell(dtype, B, H, E):
         assert close(dg1, dg2) and close(dcp1, dcp2)
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('R,E,H,V,gather', [(640, 512, 512, 10000, True), (37, 16, 32, 50, True), (64, 256, 1024, 1000, False)])
+def test_fused_decode_step_kernels_equal_the_launches_they_replace(dtype, R, E, H, V, gather):
+    """capmi_decode_prep = capmi_embedding_fwd + capmi_gather_rows of h into the [embedding | g | h] operand (:84-88);
+    capmi_lstm_cell_sentinel_fwd = capmi_gather_rows of c + capmi_lstm_cell_fwd + capmi_sentinel_fwd (:87-92); the grouped
+    p_hid || sent_emb launch (capmi_igemm_nt_group with bias / activation, 64 x 64 tiles) = two capmi_igemm_nt calls --
+    all bit for bit."""
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(R + H)
+    T_ = tdt[dtype]
+    ids = rng.randint(0, V, R).astype(np.int64)
+    ids[::7] = 0                                                       # padding rows
+    IDS = dev(ids, torch.int64)
+    table = dev(rng.standard_normal((V, E)), T_)
+    hsrc, csrc = dev(rng.standard_normal((R, H)), T_), dev(rng.standard_normal((R, H)), T_)
+    rows = dev(rng.randint(0, R, R).astype(np.int32), torch.int32) if gather else None
+    ld = E + 2 * H
+    XH = torch.full((R, ld), 7.0, dtype=T_, device=DEV)
+    _lib.call('capmi_decode_prep', p(IDS), p(table), p(hsrc), p(rows), p(XH), R, E, H, V, ld, E + H, 0, code[dtype], stream())
+    X0 = torch.zeros((R, E), dtype=T_, device=DEV)
+    _lib.call('capmi_embedding_fwd', p(IDS), p(table), p(X0), R, E, V, E, 0, code[dtype], stream())
+    Hg = torch.zeros((R, H), dtype=T_, device=DEV)
+    Cg = torch.zeros((R, H), dtype=T_, device=DEV)
+    if gather:
+        _lib.call('capmi_gather_rows', p(hsrc), p(rows), p(Hg), R, H, code[dtype], stream())
+        _lib.call('capmi_gather_rows', p(csrc), p(rows), p(Cg), R, H, code[dtype], stream())
+    else:
+        Hg.copy_(hsrc); Cg.copy_(csrc)
+    torch.cuda.synchronize()
+    assert torch.equal(XH[:, :E], X0) and torch.equal(XH[:, E + H:], Hg) and bool((XH[:, E:E + H] == 7.0).all())
+    assert not bool(XH[::7, :E].any())
+    GS = dev(rng.standard_normal((R, 5 * H)), T_)
+    h1, c1, s1 = (torch.zeros((R, H), dtype=T_, device=DEV) for _ in range(3))
+    _lib.call('capmi_lstm_cell_sentinel_fwd', p(GS), 5 * H, p(csrc), p(rows), p(h1), p(c1), p(s1), R, H, code[dtype], stream())
+    G4 = GS[:, :4 * H].contiguous()
+    SG = GS[:, 4 * H:].contiguous()
+    h2, c2, s2 = (torch.zeros((R, H), dtype=T_, device=DEV) for _ in range(3))
+    _lib.call('capmi_lstm_cell_fwd', p(G4), p(Cg), p(h2), p(c2), R, H, code[dtype], stream())
+    _lib.call('capmi_sentinel_fwd', p(SG), p(c2), p(s2), R * H, code[dtype], stream())
+    torch.cuda.synchronize()
+    assert torch.equal(h1, h2) and torch.equal(c1, c2) and torch.equal(s1, s2)
+    # grouped projections with bias / activation
+    w7, w9 = dev(rng.standard_normal((H, H)) / np.sqrt(H), T_), dev(rng.standard_normal((H, H)) / np.sqrt(H), T_)
+    b7, b9 = dev(rng.standard_normal(H), torch.float32), dev(rng.standard_normal(H), torch.float32)
+    P1, S1 = torch.zeros((R, H), dtype=T_, device=DEV), torch.zeros((R, H), dtype=T_, device=DEV)
+    P2, S2 = torch.zeros((R, H), dtype=T_, device=DEV), torch.zeros((R, H), dtype=T_, device=DEV)
+    calls = (_lib.NtCall * 2)()
+    for cl, (xin, w_, b_, out, act) in zip(calls, ((h1, w7, b7, P1, _lib.ACT_TANH), (s1, w9, b9, S1, _lib.ACT_NONE))):
+        cl.x, cl.w, cl.y, cl.g = p(xin), p(w_), p(out), _lib.gemm_geom(R, H)
+        cl.N, cl.ldw, cl.ldy = H, H, H
+        cl.bias, cl.act = p(b_), act
+    _lib.call('capmi_igemm_nt_group', calls, 2, code[dtype], stream())
+    g = _lib.gemm_geom(R, H)
+    _lib.call('capmi_igemm_nt', p(h1), p(w7), p(P2), g, H, H, H, p(b7), None, 0, None, 0, None, _lib.ACT_TANH, 0, 0, code[dtype], stream())
+    _lib.call('capmi_igemm_nt', p(s1), p(w9), p(S2), g, H, H, H, p(b9), None, 0, None, 0, None, _lib.ACT_NONE, 0, 0, code[dtype], stream())
+    torch.cuda.synchronize()
+    assert torch.equal(P1, P2) and torch.equal(S1, S2)
+    assert float(P1.float().abs().max()) <= 1.0 and float(P1.float().abs().max()) > 0.5
+
+
 def _attn_ref(Ve, Vt, q, se, s, pp, w10, b10, T, B, K, H, slots):
     """Oracle of one attention call, rows time-major; returns out, alpha."""
     M = T * B
