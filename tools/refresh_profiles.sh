@@ -26,5 +26,20 @@ timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --ker
 timeout -k 10 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_mfma" -- python3 bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-extras --no-roofline > "$out/pmc_mfma.json" 2> "$out/pmc_mfma.err"
 python3 tools/pmc_mfma.py "$out/pmc_cal" "$out/pmc_mfma" "$out/${tag}_pmc_mfma_busy.txt" 3
 rm -rf "$out/pmc_cal" "$out/pmc_mfma"
+# BASELINE configs[4]: kernel table of the beam-5 decode at batch 128
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$out/dec" -- python3 bench.py --decode --steps 10 --warmup 3 > "$out/decode_under_rocprof.json" 2> "$out/dec.err"
+python3 tools/trace_by_shape.py "$out/dec" 13 > "$out/${tag}_decode_beam5_by_shape.txt"
+rm -rf "$out/dec"
+# operand-path batch norm (capmi_igemm_nt_bnact), levels 0 / 1 / 2: step time (3 alternating runs each) and the per-queue kernel tables
+{
+  echo "# CAPMI_INBN A/B on one box: ms per step, images/s (bench.py --steps 40 --warmup 8, three alternating runs)"
+  for i in 1 2 3; do for e in CAPMI_INBN=0 CAPMI_INBN=1 CAPMI_INBN=2; do
+    r=$(env $e python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-extras --no-roofline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['value'])")
+    echo "$e  $r"
+  done; done
+} > "$out/${tag}_inbn_ab.txt"
+bash tools/prof_ab.sh "$out/inbn" CAPMI_INBN=0 CAPMI_INBN=1 CAPMI_INBN=2
+for i in 1 2 3; do { echo; echo "# $(cat $out/inbn/env_$i.txt): kernel time per queue (rocprofv3 --kernel-trace of bench.py --steps 10 --warmup 3)"; head -26 "$out/inbn/by_queue_$i.txt"; echo "# ... per shape (the convolutions that carry the operand path, and bn_apply):"; grep -E "halo3|inbn|bn_apply|igemm_nt_glds_kernel<(64, 128|128, 128)" "$out/inbn/by_shape_$i.txt" | head -24; } >> "$out/${tag}_inbn_ab.txt"; done
+rm -rf "$out/inbn"
 rm -rf "$out/stats" "$out/trace" "$out/pmc_fetch" "$out/pmc_write"
 ls -la "$out"
