@@ -108,6 +108,15 @@ int capmi_igemm_nt_bnact(const void* x_raw, const void* w, void* y, const capmi_
                          const float* in_mean, const float* in_coef_a, const float* in_offset, int in_act,
                          float* stats, int dtype, void* stream);
 
+/* Plain product y[M][N] = x[M][K] . w[N][K]^T with a LONG reduction and a SMALL output (the tied projection's data
+ * gradient, dR = dlogits . Emb: model_adaAttention_aic.py:25 backward, [T*B][V] x [V][E] -- 40 output tiles for 256 CUs):
+ * K is split over workgroups into f32 slabs in ws (capmi_igemm_nt_splitk_ws_bytes(M, N, K, dtype) bytes; 0 = this shape
+ * is not split) and a second launch adds the slabs in a fixed order (deterministic).  No bias / activation / statistics;
+ * without enough workspace, or for shapes the split does not pay for, it is capmi_igemm_nt. */
+long long capmi_igemm_nt_splitk_ws_bytes(int M, int N, int K, int dtype);
+int capmi_igemm_nt_splitk(const void* x, const void* w, void* y, int M, int K, int ldx, int N, int ldw, int ldy,
+                          float* ws, long long ws_bytes, int dtype, void* stream);
+
 /* Several independent capmi_igemm_nt products with disjoint outputs (the output-parity classes of a
  * strided convolution's data gradient; the p_hid / sent_emb projections of a decode step,
  * model_adaAttention_aic.py:99,104: small GEMMs that under-fill the chip one at a time), issued

@@ -44,6 +44,7 @@ SIGNATURES = {
     'capmi_igemm_nt_bnact': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     'capmi_igemm_nt_bnred': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'capmi_igemm_nt_group': [ctypes.POINTER(NtCall), _i, _i, _p],
+    'capmi_igemm_nt_splitk': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
     'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
     'capmi_colsum': [_p, _i, _i, _i, _p, _i, _p],
     'capmi_im2col_stem': [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
@@ -183,6 +184,8 @@ def lib():
             fn.restype = ctypes.c_int
         L.capmi_igemm_tn_ws_bytes.argtypes = [_i, _i, _i, _i]
         L.capmi_igemm_tn_ws_bytes.restype = ctypes.c_longlong
+        L.capmi_igemm_nt_splitk_ws_bytes.argtypes = [_i, _i, _i, _i]
+        L.capmi_igemm_nt_splitk_ws_bytes.restype = ctypes.c_longlong
         L.capmi_plan_entry_count.restype = ctypes.c_int
         L.capmi_plan_entry_name.argtypes = [_i]
         L.capmi_plan_entry_name.restype = ctypes.c_char_p

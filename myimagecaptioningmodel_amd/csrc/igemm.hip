@@ -47,6 +47,7 @@ struct IGemmArgs {
     capmi_conv_geom g;
     FastDiv fd_hw, fd_w;             // division by Ho*Wo and by Wo
     int act, dact, out_f32;
+    int ksplit, kper;                // split-K over workgroups (capmi_igemm_nt_splitk): split s multiplies k in [s * kper, (s + 1) * kper) into f32 slab s
     // fused batch-norm backward reduction (data-gradient launches): for each of `nred` layers that take
     // this launch's OUTPUT as their dy, per-workgroup column sums of dz and dz*(x-mean)*invstd
     int nred;
@@ -334,7 +335,8 @@ __device__ __forceinline__ void inbn_coef(const float* tab, int c0, f32x4 (&cf)[
 
 // ------------------------------------------------------------------ shared epilogue of the tiled NT kernels
 template <typename T, int BM, int BN, int WMW, bool RED = false>
-__device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred) {
+__device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred,
+                                            int64_t slab_off = 0) {      // f32 elements added to y (split-K: this split's slab)
     constexpr int WNW = 4 / WMW, RW = BM / WMW, WN = BN / WNW, TM = RW / 16, TN = WN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNW, wn = wave % WNW;
@@ -427,7 +429,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                         for (int j = 0; j < TN; ++j) t[j] = (float)py[r][j];
                         dact_run<TN>(v, t, a.dact);
                     }
-                    if (a.out_f32) store_run<float, TN>((float*)a.y + rows[r] * a.ldy + col0, v);
+                    if (a.out_f32) store_run<float, TN>((float*)a.y + slab_off + rows[r] * a.ldy + col0, v);
                     else store_run<T, TN>((T*)a.y + rows[r] * a.ldy + col0, v);
                     if constexpr (RED) {
 #pragma unroll
@@ -462,7 +464,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         if (j < nv) {
-                            if (a.out_f32) ((float*)a.y)[row * a.ldy + col0 + j] = v[j];
+                            if (a.out_f32) ((float*)a.y)[slab_off + row * a.ldy + col0 + j] = v[j];
                             else ((T*)a.y)[row * a.ldy + col0 + j] = from_f32<T>(v[j]);
                         }
                     if constexpr (RED) {
@@ -750,6 +752,14 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     const int grp = KG == 1 ? 0 : (int)(threadIdx.x >> 8);       // k-group of this wave
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;   // position inside the group
     const int tiles_n = (a.N + BN - 1) / BN;
+    int split = 0, kbeg = 0, kend = a.K;
+    if (LIN == 1 && a.ksplit > 1) {     // split-K over workgroups: blocks [s * tiles, (s + 1) * tiles) work k in [s * kper, (s + 1) * kper)
+        nblocks /= a.ksplit;
+        split = block / nblocks;
+        block -= split * nblocks;
+        kbeg = split * a.kper;
+        kend = min(a.K, kbeg + a.kper);
+    }
     const int tile = xcd_swizzle(block, nblocks);
     const int m0 = (tile / tiles_n) * BM;
     const int n0 = (tile % tiles_n) * BN;
@@ -771,6 +781,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         wrow[i] = W + (int64_t)(wok[i] ? n : 0) * a.ldw;
     }
     KPos kp = k_pos(chunk * 8 + grp * BK, a.g);
+    if constexpr (LIN == 1) kp.k += kbeg;
     const T* zero = reinterpret_cast<const T*>(capmi_zero_page);
     // addressing mode LIN: 1 = 1x1 / no padding (any stride): A(m, k) = x[base(m) + k], no tap arithmetic in the
     // loop; 2 = up == 1 and Cin >= BK: taps tracked with selects, no branches; 0 = general (a_offset)
@@ -784,7 +795,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         for (int i = 0; i < ACNT; ++i) {
             const T* src;
             if constexpr (LIN == 1) {
-                src = (arow[i] && kp.k < a.K) ? arow[i] + kp.k : zero;
+                src = (arow[i] && kp.k < kend) ? arow[i] + kp.k : zero;
             } else if constexpr (LIN == 2) {
                 const int hn = rp[i].hb + kp.r, wn = rp[i].wb + kp.q;
                 const bool ok = arow[i] && kp.k < a.K && (unsigned)hn < (unsigned)Hi && (unsigned)wn < (unsigned)Wi;
@@ -799,7 +810,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         }
 #pragma unroll
         for (int i = 0; i < BCNT; ++i) {
-            const T* src = (wok[i] && kp.k < a.K) ? wrow[i] + kp.k : zero;
+            const T* src = (wok[i] && kp.k < (LIN == 1 ? kend : a.K)) ? wrow[i] + kp.k : zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(base + AOPB + i * 4096), 16, 0, 0);
         }
@@ -822,7 +833,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nkt = (a.K + KG * BK - 1) / (KG * BK);
+    const int nkt = (kend - kbeg + KG * BK - 1) / (KG * BK);
     const int fr = lane & 15, fg = lane >> 4;
     // fragment byte offsets inside a stage (swizzled chunk position)
     int aoff[TM], boff[TN];
@@ -905,7 +916,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] += xch[(g * TM * TN + i * TN + j) * 256 + tid];
     }
-    nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
+    nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(smem), (int64_t)split * a.M * a.ldy);
 }
 
 template <int BM, int BN, int NST, bool RED = false, int LIN = 0>
@@ -1933,7 +1944,7 @@ static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const
     CAPMI_CHECK(g->os <= 1 || (!stats && g->Hof > 0 && g->Wof > 0 && (g->Ho - 1) * g->os + g->oh0 < g->Hof && (g->Wo - 1) * g->os + g->ow0 < g->Wof),
                 "capmi_igemm_nt: bad output-scatter geometry");
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.bn_mean = nullptr; a.bn_a = nullptr; a.addend = addend; a.ysaved = ysaved; a.stats = stats;
-    a.in_mean = nullptr; a.in_a = nullptr; a.in_off = nullptr; a.in_act = 0;
+    a.in_mean = nullptr; a.in_a = nullptr; a.in_off = nullptr; a.in_act = 0; a.ksplit = 1; a.kper = 0;
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldw = ldw; a.ldy = ldy; a.ld_addend = ld_addend; a.ld_saved = ld_saved;
     a.g = *g; a.act = act; a.dact = dact; a.out_f32 = out_f32;
@@ -2099,6 +2110,61 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
                               int ld_addend, const void* ysaved, int ld_saved, float* stats,
                               int act, int dact, int out_f32, int dtype, void* stream) {
     return igemm_nt_impl(x, w, y, g, N, ldw, ldy, bias, addend, ld_addend, ysaved, ld_saved, stats, act, dact, out_f32, 0, nullptr, dtype, stream);
+}
+
+// ------------------------------------------------------------------ split-K over workgroups (deep K, few output tiles)
+// y[m][n] = sum_s slab[s][m][n], rounded to T once: 16-byte slab loads, fixed summation order (deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void nt_splitk_reduce_kernel(const float* __restrict__ slab, int S, int64_t MN, int N, int ldy, T* y) {
+    const int64_t n4 = MN / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 acc = reinterpret_cast<const f32x4*>(slab)[i];
+        for (int s = 1; s < S; ++s) acc += reinterpret_cast<const f32x4*>(slab + (int64_t)s * MN)[i];
+        const int64_t e = i * 4, row = e / N;
+        const int col = (int)(e - row * N);
+        T* o = y + row * ldy + col;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = from_f32<T>(acc[k]);
+    }
+}
+static int nt_splitk_plan(int M, int N, int K, int* kper) {      // number of splits (1: not worth it) and the k range of one
+    const int tiles = cdiv(M, 128) * cdiv(N, 128);
+    if (K < 4096 || tiles > 128 || N % 4 != 0) return 1;
+    int S = 256 / tiles;
+    if (S > cdiv(K, 1024)) S = cdiv(K, 1024);                    // >= 32 k-steps per split
+    if (S < 2) return 1;
+    const int per = cdiv(cdiv(K, S), 32) * 32;
+    *kper = per;
+    return cdiv(K, per);
+}
+extern "C" long long capmi_igemm_nt_splitk_ws_bytes(int M, int N, int K, int dtype) {
+    int kper = 0;
+    const int S = dtype == CAPMI_BF16 ? nt_splitk_plan(M, N, K, &kper) : 1;
+    return S > 1 ? (long long)S * M * N * 4 : 0;
+}
+/* A plain product y[M][N] = x[M][K] . w[N][K]^T (no bias / activation / statistics) whose reduction is long and whose output
+ * is small -- the tied projection's data gradient, [T*B][V] x [V][E] (model_adaAttention_aic.py:25 backward): 40 output
+ * tiles cannot fill 256 CUs however many waves work each.  K is split over workgroups into f32 slabs (ws, at least
+ * capmi_igemm_nt_splitk_ws_bytes) that a second launch adds up in a fixed order; shapes the split does not pay for (or a
+ * missing workspace) run as capmi_igemm_nt. */
+extern "C" int capmi_igemm_nt_splitk(const void* x, const void* w, void* y, int M, int K, int ldx, int N, int ldw, int ldy,
+                                     float* ws, long long ws_bytes, int dtype, void* stream) {
+    const capmi_conv_geom g = {M, 1, 1, K, 1, 1, 1, 1, 1, 1, 0, ldx, 0, 0, 0, 0, 0};
+    int kper = 0;
+    const int S = dtype == CAPMI_BF16 ? nt_splitk_plan(M, N, K, &kper) : 1;
+    if (S <= 1 || !ws || ws_bytes < (long long)S * M * N * 4)
+        return igemm_nt_impl(x, w, y, &g, N, ldw, ldy, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 0, 0, nullptr, dtype, stream);
+    IGemmArgs a;
+    if (nt_prepare(a, x, w, ws, &g, N, ldw, N, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, 0, 1, 0, nullptr, dtype)) return 1;
+    a.ksplit = S;
+    a.kper = kper;
+    const int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 128, 3, false, 1>), dim3((unsigned)(tiles * S)), dim3(256), 0, st, a);
+    const int64_t MN = (int64_t)M * N;
+    hipLaunchKernelGGL(nt_splitk_reduce_kernel<bf16>, dim3(ew_grid(MN / 4)), dim3(256), 0, st, ws, S, MN, N, ldy, (bf16*)y);
+    CAPMI_LAUNCH_CHECK("capmi_igemm_nt_splitk");
+    return 0;
 }
 
 /* Convolution + INFERENCE batch norm + residual + activation in one launch (the exported model of infer.py: every

@@ -54,6 +54,7 @@ struct Entry {
 const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_igemm_nt),
     CAPMI_ENTRY(capmi_igemm_nt_group),
+    CAPMI_ENTRY(capmi_igemm_nt_splitk),
     CAPMI_ENTRY(capmi_igemm_nt_bn),
     CAPMI_ENTRY(capmi_igemm_nt_bnact),
     CAPMI_ENTRY(capmi_igemm_nt_bnred),

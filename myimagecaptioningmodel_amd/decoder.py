@@ -275,7 +275,12 @@ class DecoderRunner:
         self._wgrad(plan, _p(self.R), M, E, _p(self.dlogits), V, g_('word_embedding'), ldy=Vld)
         if self.overlap_wgrad:
             plan.record(('dec', 'tied projection'), 1)      # embedding_bwd adds into the same rows (ordered below)
-        self._gemm(plan, _p(self.dlogits), M, Vld, _p(WT('word_embedding')), E, _p(self.dR), ldw=Vld)
+        # [T*B][V] x [V][E]: a long reduction into 40 output tiles -- split over workgroups (f32 slabs in the main lane's scratch)
+        if os.environ.get('CAPMI_SPLITK', '1') == '0':
+            self._gemm(plan, _p(self.dlogits), M, Vld, _p(WT('word_embedding')), E, _p(self.dR), ldw=Vld)
+        else:
+            plan.add('capmi_igemm_nt_splitk', _p(self.dlogits), _p(WT('word_embedding')), _p(self.dR), M, Vld, Vld, E, Vld, E,
+                     _p(wgrad_workspace(self.store.device, 0)), WGRAD_WS_BYTES, code)
         # fc_12 (:24) and fc_11 + tanh (:115)
         self._wgrad(plan, _p(self.O), M, H, _p(self.dR), E, g_(w12))
         self._colsum(plan, _p(self.dR), M, E, g_(b12))

@@ -104,6 +104,39 @@ def test_gemm_nt_epilogues(dtype, M, N, K):
         check(st[pi, :, 1], ((blk - blk.mean(0)) ** 2).sum(0), dtype, scale=(blk ** 2).sum(0).max(), name='part M2')
 
 
+@pytest.mark.parametrize('M,N,K', [(1216, 512, 10000), (1856, 1024, 20000), (640, 512, 4096), (300, 96, 8200), (1216, 512, 1024)])
+def test_split_k_product_equals_the_plain_one(M, N, K):
+    """capmi_igemm_nt_splitk (the tied projection's data gradient, model_adaAttention_aic.py:25 backward: [T*B][V] x [V][E])
+    against capmi_igemm_nt on the same operands and against the oracle's matmul: same product, f32 slabs added in a fixed
+    order and rounded to bf16 once; bit-reproducible; shapes outside the split fall through to the plain kernel."""
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(M + K)
+    x = rnd(rng.standard_normal((M, K)), 'bf16')
+    w = rnd(rng.standard_normal((N, K)) / np.sqrt(K), 'bf16')
+    X, Wt = dev(x, torch.bfloat16), dev(w, torch.bfloat16)
+    need = _lib.lib().capmi_igemm_nt_splitk_ws_bytes(M, N, K, _lib.BF16)
+    assert (need > 0) == (K >= 4096 and ((M + 127) // 128) * ((N + 127) // 128) <= 128 and need % (M * N * 4) == 0)
+    ws = torch.zeros(max(need, 16) // 4, dtype=torch.float32, device=DEV)
+    Y1, Y2, Y3 = (torch.zeros((M, N), dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    _KEEP.extend([ws, Y1, Y2, Y3])
+    _lib.call('capmi_igemm_nt_splitk', p(X), p(Wt), p(Y1), M, K, K, N, K, N, p(ws), ws.numel() * 4, _lib.BF16, stream())
+    _lib.call('capmi_igemm_nt_splitk', p(X), p(Wt), p(Y3), M, K, K, N, K, N, p(ws), ws.numel() * 4, _lib.BF16, stream())
+    g = _lib.gemm_geom(M, K)
+    _lib.call('capmi_igemm_nt', p(X), p(Wt), p(Y2), g, N, K, N, None, None, 0, None, 0, None, 0, 0, 0, _lib.BF16, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(Y1, Y3)
+    want = x @ w.T
+    check(host(Y1), want, 'bf16', name='split-K product')
+    assert float((Y1.float() - Y2.float()).abs().max()) <= 2 ** -7 * max(1.0, float(Y2.float().abs().max()))
+    if need == 0:
+        assert torch.equal(Y1, Y2)
+    # no workspace: the plain kernel
+    Y4 = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    _lib.call('capmi_igemm_nt_splitk', p(X), p(Wt), p(Y4), M, K, K, N, K, N, None, 0, _lib.BF16, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(Y4, Y2)
+
+
 def _nhwc(x):
     return np.ascontiguousarray(x.transpose(0, 2, 3, 1))
 
