@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from myimagecaptioningmodel_amd import _lib, arch  # noqa: E402
+from myimagecaptioningmodel_amd.encoder import dgrad_class_offsets  # noqa: E402
 
 B, S = int(os.environ.get('B', 64)), 224
 dev = 'cuda:0'
@@ -67,7 +68,27 @@ for name, h, w, cin, cout, k, s, pad, ho, wo in rows:
     g = _lib.ConvGeom(B, h, w, cin, ho, wo, k, k, s, 1, pad, cin)
     gd = _lib.ConvGeom(B, ho, wo, cout, h, w, k, k, 1, s, k - 1 - pad, cout)
     f = lambda st: _lib.lib().capmi_igemm_nt(p(x), p(wt), p(y), g, cout, K, cout, None, None, 0, None, 0, p(ws), 0, 0, 0, code, st)
-    d = lambda st: _lib.lib().capmi_igemm_nt(p(y), p(wtT), p(dx), gd, cin, k * k * cout, cin, None, None, 0, None, 0, None, 0, 0, 0, code, st)
+    if s == 1:
+        d = lambda st: _lib.lib().capmi_igemm_nt(p(y), p(wtT), p(dx), gd, cin, k * k * cout, cin, None, None, 0, None, 0, None, 0, 0, 0, code, st)
+    else:
+        # what the engine launches (encoder.plan_backward): one dense GEMM per output-parity class over the compact pixel grid,
+        # the classes as ONE grouped launch (+ a zero fill when the classes do not cover every pixel: 1x1 / stride 2)
+        classes = dgrad_class_offsets(k, s, pad)
+        calls = (_lib.NtCall * len(classes))()
+        wcls = []
+        for cl, ((ph, pw), (d0h, d0w, nkh, nkw)) in zip(calls, classes.items()):
+            hc, wc = (h - ph + s - 1) // s, (w - pw + s - 1) // s
+            wk = (torch.randn((cin, nkh * nkw * cout), device=dev) / K ** 0.5).to(bf)
+            wcls.append(wk)
+            cl.x, cl.w, cl.y = p(y), p(wk), p(dx)
+            cl.g = _lib.ConvGeom(B, ho, wo, cout, hc, wc, nkh, nkw, 1, 1, -d0h, cout, s, ph, pw, h, w)
+            cl.N, cl.ldw, cl.ldy = cin, nkh * nkw * cout, cin
+        covered = len(classes) == s * s
+
+        def d(st, calls=calls, n=len(classes), covered=covered):
+            if not covered:
+                _lib.lib().capmi_fill_f32(p(dx), 0.0, dx.numel() // 2, st)
+            return _lib.lib().capmi_igemm_nt_group(calls, n, code, st)
     wsb = _lib.wgrad_workspace(dev)
     wg = lambda st: _lib.lib().capmi_igemm_tn_wgrad(p(x), p(y), p(dw), g, cout, cout, K, p(wsb), _lib.WGRAD_WS_BYTES, code, st)
     tf, td, tw = timeit(f), timeit(d), timeit(wg)
