@@ -2688,7 +2688,12 @@ static int tn_splits(int M, int N, int K, int bno, int bko, int* per_out) {
     long long by_ws = (6ll << 20) / (out_elems > 0 ? out_elems : 1);
     if (by_ws < 1) by_ws = 1;
     static const int slots_env = getenv("CAPMI_TN_SLOTS") ? atoi(getenv("CAPMI_TN_SLOTS")) : 0;      // experiment knob
-    const int slots = slots_env > 0 ? slots_env * (bno >= 128 ? 1 : 2) : 256 * (bno >= 128 ? 1 : 2);
+    int slots = slots_env > 0 ? slots_env * (bno >= 128 ? 1 : 2) : 256 * (bno >= 128 ? 1 : 2);
+    // The one weight gradient with more than half a million reduction rows is the stem's, and the stem's is the LAST launch of
+    // the backward pass: nothing runs beside it (the main lane is waiting for it), so it fills the chip instead of leaving
+    // room -- 97.7 -> 71.3 us alone (tools/wgrad_probe.py), on the step's critical tail.
+    static const int stem_fill = getenv("CAPMI_STEM_FILL") ? atoi(getenv("CAPMI_STEM_FILL")) : 1;      // experiment knob
+    if (!slots_env && stem_fill && M >= (1 << 19)) slots *= 2;
     int want = slots / tiles;
     int max_splits = cdiv(M, 256);
     if (max_splits > by_ws) max_splits = (int)by_ws;

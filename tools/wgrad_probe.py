@@ -10,14 +10,19 @@ from myimagecaptioningmodel_amd import _lib  # noqa: E402
 
 dev = 'cuda:0'
 B = int(os.environ.get('B', 64))
-shapes = [(56, 64, 64, 1), (56, 256, 64, 1), (56, 64, 256, 1), (56, 64, 64, 3), (56, 256, 128, 1), (28, 128, 128, 3)]
+shapes = [(56, 64, 64, 1), (56, 256, 64, 1), (56, 64, 256, 1), (56, 64, 64, 3), (56, 256, 128, 1), (28, 128, 128, 3), ('stem', 16, 64, 4)]
 ws = _lib.wgrad_workspace(dev)
 for hw, cin, cout, k in shapes:
+    if hw == 'stem':        # the 7x7 / stride-2 stem as the engine runs it: a 4x4 / stride-1 conv on the 2x2 space-to-depth image (115 x 115 x 16 -> 112 x 112)
+        hw, hi = 112, 115
+        x = torch.randn((B, hi, hi, cin), device=dev).to(torch.bfloat16)
+        g = _lib.ConvGeom(B, hi, hi, cin, hw, hw, k, k, 1, 1, 0, cin)
+    else:
+        x = torch.randn((B, hw, hw, cin), device=dev).to(torch.bfloat16)
+        g = _lib.ConvGeom(B, hw, hw, cin, hw, hw, k, k, 1, 1, k // 2, cin)
     M, K = B * hw * hw, k * k * cin
-    x = torch.randn((B, hw, hw, cin), device=dev).to(torch.bfloat16)
     dy = torch.randn((B, hw, hw, cout), device=dev).to(torch.bfloat16)
     dw = torch.zeros((cout, K), device=dev)
-    g = _lib.ConvGeom(B, hw, hw, cin, hw, hw, k, k, 1, 1, k // 2, cin)
     st = torch.cuda.current_stream().cuda_stream
 
     def run():
