@@ -281,6 +281,11 @@ int capmi_act_bwd(const void* dy, const void* y, void* dx, int accumulate, int64
 int capmi_mean_rows(const void* x, void* out, int B, int K, int C, int dtype, void* stream);
 int capmi_mean_rows_bwd(const void* dout, void* dx, int B, int K, int C, int dtype, void* stream);
 
+/* The caption feed of a train step (reader.py:45-47: int64 [B][L], <start> first, right-padded with 0) as the decoder reads it:
+ * ids[t*B + b] = caption[b][t] (the source words caption[:, :-1], model_adaAttention_aic.py:164, time-major :60) and
+ * tgt[t*B + b] = caption[b][t + 1] (the targets caption[:, 1:], :163), t = 0 .. L-2.  One launch. */
+int capmi_caption_feed(const int64_t* caption, int64_t* ids, int64_t* tgt, int B, int L, void* stream);
+
 /* fluid.embedding(padding_idx) (model_adaAttention_aic.py:28-32): out[m][0..E) = table[ids[m]]
  * (zeros for padding_idx), written with row stride ldo.  bwd: dtable[ids[m]] += dout[m] (f32
  * atomics; padding rows skipped). */

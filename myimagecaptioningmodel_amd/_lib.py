@@ -71,6 +71,7 @@ SIGNATURES = {
     'capmi_mean_rows': [_p, _p, _i, _i, _i, _i, _p],
     'capmi_mean_rows_bwd': [_p, _p, _i, _i, _i, _i, _p],
     'capmi_embedding_fwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_caption_feed': [_p, _p, _p, _i, _i, _p],
     'capmi_embedding_bwd': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'capmi_bcast_rows': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
     'capmi_bcast_rows_bwd': [_p, _p, _i, _i, _i, _i, _i, _i, _p],
@@ -251,6 +252,18 @@ def _float_bits(x):
     return struct.unpack('<I', struct.pack('<f', float(x)))[0]
 
 
+class PtrSlot:
+    """A device pointer argument that is re-read before every run of a plan (like the ctypes.c_float of the Adam step size):
+    the feed tensor of a step can then be the caller's own device tensor instead of a copy of it."""
+
+    def __init__(self, value=0):
+        self.value = int(value)
+
+
+def _patch_bits(src):
+    return _float_bits(src.value) if isinstance(src, ctypes.c_float) else int(src.value) & 0xFFFFFFFFFFFFFFFF
+
+
 def _slot(value, ctype):
     """One argument as the 8-byte slot capmi_plan_run expects; (bits, patch source or None)."""
     if ctype is _f:
@@ -259,6 +272,8 @@ def _slot(value, ctype):
         return _float_bits(value), None
     if value is None:
         return 0, None
+    if isinstance(value, PtrSlot):
+        return int(value.value) & 0xFFFFFFFFFFFFFFFF, value
     if isinstance(value, (ctypes.Structure, ctypes.Array)):
         return ctypes.addressof(value), None            # host struct kept alive by Plan._keep
     if isinstance(value, ctypes.c_void_p):
@@ -401,7 +416,7 @@ class Plan:
         if c is None:
             c = self._compiled[key] = self._compile(lanes)
         for row, slot, src in c['patches']:
-            c['table'][row].args[slot] = _float_bits(src.value)
+            c['table'][row].args[slot] = _patch_bits(src)
         streams = (ctypes.c_void_p * 3)(stream, stream, stream)
         if lanes:
             for l, s in c['side']['streams'].items():
@@ -414,7 +429,7 @@ class Plan:
         L = lib()
         if not lanes:
             for fn, name, args in self.calls:
-                if fn is not None and fn(*args, stream) != 0:
+                if fn is not None and fn(*[a.value if isinstance(a, PtrSlot) else a for a in args], stream) != 0:
                     raise CapmiError('%s failed: %s' % (name, last_error()))
             return
         c = self._compiled.get(('py', len(self.calls)))
@@ -439,7 +454,7 @@ class Plan:
                 else:
                     rc = 0
             else:
-                rc = getattr(fn, 'fn', fn)(*args, ptrs[getattr(fn, 'lane', 0)])
+                rc = getattr(fn, 'fn', fn)(*[a.value if isinstance(a, PtrSlot) else a for a in args], ptrs[getattr(fn, 'lane', 0)])
             if rc != 0:
                 raise CapmiError('%s failed: %s' % (name, last_error()))
         for l in others:

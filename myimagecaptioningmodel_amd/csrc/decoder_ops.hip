@@ -26,6 +26,22 @@ extern "C" int capmi_embedding_fwd(const int64_t* ids, const void* table, void* 
     CAPMI_LAUNCH_CHECK("capmi_embedding_fwd");
     return 0;
 }
+// caption [B][L] (the reader's feed, reader.py:45-47) -> time-major source words ids[t*B + b] = caption[b][t] (caption[:, :-1],
+// model_adaAttention_aic.py:164,60) and targets tgt[t*B + b] = caption[b][t + 1] (caption[:, 1:], :163), t < L - 1: one launch
+// instead of two slice + transpose + copy chains of the host framework in front of every step
+__global__ __launch_bounds__(256) void caption_feed_kernel(const int64_t* __restrict__ caption, int64_t* ids, int64_t* tgt, int B, int L) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= (L - 1) * B) return;
+    const int t = e / B, b = e - t * B;
+    ids[e] = caption[(int64_t)b * L + t];
+    tgt[e] = caption[(int64_t)b * L + t + 1];
+}
+extern "C" int capmi_caption_feed(const int64_t* caption, int64_t* ids, int64_t* tgt, int B, int L, void* stream) {
+    CAPMI_CHECK(caption && ids && tgt && B >= 1 && L >= 2, "capmi_caption_feed: bad arguments");
+    hipLaunchKernelGGL(caption_feed_kernel, dim3(cdiv((int64_t)(L - 1) * B, 256)), dim3(256), 0, (hipStream_t)stream, caption, ids, tgt, B, L);
+    CAPMI_LAUNCH_CHECK("capmi_caption_feed");
+    return 0;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const T* __restrict__ dout, float* dtable,
                                                             int M, int E, int V, int ldo, int padding_idx) {

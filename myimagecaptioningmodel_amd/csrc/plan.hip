@@ -84,6 +84,7 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_mean_rows),
     CAPMI_ENTRY(capmi_mean_rows_bwd),
     CAPMI_ENTRY(capmi_embedding_fwd),
+    CAPMI_ENTRY(capmi_caption_feed),
     CAPMI_ENTRY(capmi_embedding_bwd),
     CAPMI_ENTRY(capmi_bcast_rows),
     CAPMI_ENTRY(capmi_bcast_rows_bwd),

@@ -18,7 +18,7 @@ import os
 import torch
 
 from . import arch
-from ._lib import ACT_CODES, WGRAD_WS_BYTES, ConvGeom, NtCall, lib, wgrad_workspace
+from ._lib import ACT_CODES, WGRAD_WS_BYTES, ConvGeom, NtCall, PtrSlot, lib, wgrad_workspace
 from .params import stem_s2d
 
 BN_MOMENTUM = 0.9      # fluid.layers.batch_norm defaults; MobileNetV2.py:112-117 overrides neither
@@ -26,6 +26,8 @@ BN_EPS = 1e-5
 
 
 def _p(t):
+    if isinstance(t, PtrSlot):          # a pointer the plan re-reads before every run (the caller's feed tensor)
+        return t
     return None if t is None else t.data_ptr()
 
 
@@ -226,7 +228,8 @@ class EncoderRunner:
 
     # ------------------------------------------------------------------ forward plan
     def plan_forward(self, plan, image, weights, update_running=True, is_test=False):
-        """image: f32 NCHW [B,3,S,S] device tensor (the reference feed).  weights(name) -> tensor
+        """image: f32 NCHW [B,3,S,S] device tensor (the reference feed), or a _lib.PtrSlot holding its address (re-read
+        before every run: the train step then reads the caller's tensor in place).  weights(name) -> tensor
         the kernels read (f32 master or bf16 shadow).  is_test: normalise with the running statistics (the exported
         inference model, infer.py) instead of the batch statistics (every in-training graph, quirks Q3/Q4)."""
         st, B, code = self.store, self.B, self.code

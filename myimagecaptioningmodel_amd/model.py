@@ -174,7 +174,10 @@ class CaptionEngine:
         # decoder part (2T small recurrent launches) has none and replays from a hipGraph -- keeps the host
         # time per step well below the device time
         fwd_enc, fwd_dec, fwd, bwd = Plan(), Plan(), Plan(), Plan()
-        enc.plan_forward(fwd_enc, image, self.W)
+        # the feed's address is an argument slot the plan re-reads before every run: a float32 device tensor of the caller is read
+        # in place by the first kernel (38.5 MB less to copy in front of every step at cfg 2), anything else is staged in `image`
+        image_slot = _lib.PtrSlot(image.data_ptr())
+        enc.plan_forward(fwd_enc, image_slot, self.W)
         # Where the encoder forward has a side lane anyway (projection shortcuts), the gradient buffer is zeroed there, under
         # the forward pass, instead of in front of the backward pass on the critical chain; the forward plan's final join
         # orders it before the first gradient write.  (A lane-less forward plan stays lane-less: it replays from a hipGraph.)
@@ -201,7 +204,7 @@ class CaptionEngine:
         n_dec = len(bwd)
         if need_enc_bwd:
             enc.plan_backward(bwd, self.W, self.WT, marks)
-        prog = dict(B=B, enc=enc, dec=dec, image=image, fwd=fwd, fwd_parts=[fwd_enc, fwd_dec], bwd=bwd, graph=None, marks=marks, n_dec=n_dec)
+        prog = dict(B=B, enc=enc, dec=dec, image=image, image_slot=image_slot, fwd=fwd, fwd_parts=[fwd_enc, fwd_dec], bwd=bwd, graph=None, marks=marks, n_dec=n_dec)
         return prog
 
     def _compile_eval(self, B, beam=1, is_test=False, scored=False):
@@ -283,9 +286,21 @@ class CaptionEngine:
             raise ValueError('image feed must be %s, got %s' % (tuple(prog['image'].shape), tuple(img.shape)))
         if tuple(cap.shape) != (B, cfg['sentence_length']):
             raise ValueError('caption feed must be %s, got %s' % ((B, cfg['sentence_length']), tuple(cap.shape)))
-        prog['image'].copy_(img)
-        dec.ids.copy_(cap[:, :-1].t().reshape(-1))          # source = caption[:, :-1] (:164), time-major (:60)
-        dec.tgt.copy_(cap[:, 1:].t().reshape(-1))           # target = caption[:, 1:]  (:163)
+        # Laned plans are launched eagerly (capmi_plan_run patches the slot); a plan replayed from a hipGraph has its pointers
+        # frozen at capture and reads the staging tensor
+        eager = (not self.use_graph) or (prog['fwd'].has_lanes and self.overlap_lanes and os.environ.get('CAPMI_LANES', '1') != '0')
+        if eager and img.is_contiguous() and os.environ.get('CAPMI_FEED_COPY', '0') != '1':
+            prog['image_slot'].value = img.data_ptr()       # the caller's own float32 device tensor (or the device copy just made of a host
+            prog['image_ref'] = img                         # feed): read in place; kept alive until the next feed -- the caller must not rewrite it before the step ran
+        else:
+            prog['image'].copy_(img)
+            prog['image_slot'].value = prog['image'].data_ptr()
+            prog['image_ref'] = None
+        if not cap.is_contiguous():
+            cap = cap.contiguous()
+        prog['caption_ref'] = cap
+        # source = caption[:, :-1] (:164) and target = caption[:, 1:] (:163), time-major (:60), in one launch
+        _lib.call('capmi_caption_feed', cap.data_ptr(), dec.ids.data_ptr(), dec.tgt.data_ptr(), B, cfg['sentence_length'], self._stream())
 
     # ------------------------------------------------------------------ public steps
     def forward_backward(self, image, caption):

@@ -130,7 +130,7 @@ def time_plan(plan, stream_ptr, repeats=1):
         for fn, name, args in plan.launches():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(cur)
-            rc = fn(*args, stream_ptr)
+            rc = fn(*[x.value if hasattr(x, 'value') and type(x).__name__ == 'PtrSlot' else x for x in args], stream_ptr)
             b.record(cur)
             if rc != 0:
                 raise RuntimeError('%s failed during timing' % name)

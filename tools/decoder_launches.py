@@ -24,7 +24,7 @@ for tag, plan in (('F', prog['fwd_parts'][1]), ('B', prog['bwd'])):
         es = []
         for fn, name, args in calls:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(cur); fn(*args, st); b.record(cur)
+            a.record(cur); fn(*[x.value if type(x).__name__ == "PtrSlot" else x for x in args], st); b.record(cur)
             es.append((a, b))
         torch.cuda.synchronize()
         t = [a.elapsed_time(b) * 1e3 for a, b in es]

@@ -24,7 +24,7 @@ for plan, tag in ((prog['fwd'], 'F'), (prog['bwd'], 'B')):
         es = []
         for fn, name, args in plan.launches():
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(cur); fn(*args, st); b.record(cur)
+            a.record(cur); fn(*[x.value if type(x).__name__ == "PtrSlot" else x for x in args], st); b.record(cur)
             es.append((a, b))
         torch.cuda.synchronize()
         evs.append([a.elapsed_time(b) * 1e3 for a, b in es])
