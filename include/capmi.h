@@ -245,6 +245,19 @@ int capmi_bn_bwd_reduce_spread(const void* dy, const void* x, const void* y, con
 int capmi_bn_bwd_apply_spread(const void* dy, const void* x, const void* y, const float* saved_mean, const float* saved_invstd,
                               const float* scale, float* red, const float* acc8, void* dx, int dx_accumulate, void* dres,
                               int dres_accumulate, int M, int C, int act, int dtype, void* stream);
+/* The same pair for a layer whose activated output feeds a 3x3 / stride-2 max pool and nothing else (the ResNet stem:
+ * conv -> batch_norm -> relu -> pool2d, MobileNetV2.py:88-121 conv_bn_layer + the pool of the build-defined ResNet encoders):
+ * capmi_maxpool3x3s2_bwd + capmi_bn_bwd_reduce_spread + capmi_bn_bwd_apply_spread WITHOUT materialising the pool's input
+ * gradient -- both kernels gather it from dpool [B,Ho,Wo,C] (the gradient of the pool's OUTPUT, a quarter of the size) and
+ * the forward pass's uint8 argmax map idx; x / y [B,Hi,Wi,C] are the layer's conv output and activated output.  act must
+ * be CAPMI_ACT_RELU or CAPMI_ACT_RELU6.  dy_scratch [B,Hi,Wi,C] is written only in deterministic mode, where the pair runs
+ * the three-launch path (pool backward into dy_scratch, two-stage sums through ws / red). */
+int capmi_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* saved_mean,
+                             const float* saved_invstd, float* ws, float* red, float* acc8, void* dy_scratch, int B, int Hi, int Wi,
+                             int C, int Ho, int Wo, int act, int dtype, void* stream);
+int capmi_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* saved_mean,
+                            const float* saved_invstd, const float* scale, float* red, const float* acc8, const void* dy_scratch,
+                            void* dx, int B, int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream);
 /* Inference mode (fluid batch_norm is_test=True, the exported model of infer.py): mean = running mean,
  * coef_a = scale / sqrt(running variance + eps); follow with capmi_bn_apply. */
 int capmi_bn_inference_coef(const float* scale, const float* run_mean, const float* run_var, float eps, float* mean,

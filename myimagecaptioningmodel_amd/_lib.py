@@ -66,6 +66,8 @@ SIGNATURES = {
     'capmi_bn_bwd_apply': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_reduce_spread': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_apply_spread': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
+    'capmi_bn_bwd_reduce_pool': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_bn_bwd_apply_pool': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_add_act': [_p, _p, _p, _l, _i, _i, _p],
     'capmi_act_bwd': [_p, _p, _p, _i, _l, _i, _i, _p],
     'capmi_mean_rows': [_p, _p, _i, _i, _i, _i, _p],

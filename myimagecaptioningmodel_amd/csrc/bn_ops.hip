@@ -9,6 +9,7 @@
 // (thread -> (cc, rr), ColLayout): coefficients live in registers, the row loop is pure 16-byte
 // traffic, and every formula subtracts the mean BEFORE scaling (as the reference's op does).
 #include <atomic>
+#include <type_traits>
 #include "common.h"
 
 // ------------------------------------------------------------------ statistics (standalone producer)
@@ -909,4 +910,239 @@ extern "C" int capmi_bn_bwd_apply_spread(const void* dy, const void* x, const vo
     CAPMI_CHECK(acc8 && ((uintptr_t)acc8 % 16 == 0) && C % 4 == 0, "capmi_bn_bwd_apply_spread: acc8 must be 16-byte aligned (and C a multiple of 4)");
     return bn_bwd_apply_impl(dy, x, y, saved_mean, saved_invstd, scale, red, capmi_deterministic() ? nullptr : acc8, dx, dx_accumulate, dres,
                              dres_accumulate, M, C, act, dtype, stream);
+}
+
+// ------------------------------------------------------------------ batch-norm backward straight from a max-pool's gradient
+// The stem: conv -> batch_norm -> relu -> 3x3 / stride-2 max pool (the ResNet stem; MobileNetV2.py:88-121 + the pool of the
+// build-defined ResNet encoders).  Its backward used to be three streaming launches on the step's serial tail --
+// capmi_maxpool3x3s2_bwd writes the 103 MB gradient of the pool's input, capmi_bn_bwd_reduce and capmi_bn_bwd_apply read it
+// back.  Here both batch-norm kernels GATHER that gradient from the pooled one (a quarter of the size) and the uint8 argmax
+// map: a thread owns a 2 x 2 block of input pixels x VEC channels, loads the (up to) four windows that cover it once, and the
+// pool's input gradient is never materialised.  dz = gathered dy * act'(y), rounded to T where the three-kernel path stores it.
+template <typename T> struct PoolWin {
+    static constexpr int VEC = Vec<T>::N;
+    typedef typename std::conditional<VEC == 8, uint64_t, uint32_t>::type IdxT;
+    Vec<T> dv[2][2];
+    IdxT iv[2][2];
+    bool ok[2][2];
+    __device__ __forceinline__ void load(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, int b, int i, int j, int cc, int cpr, int Ho, int Wo) {
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const int ho = i + di, wo = j + dj;
+                ok[di][dj] = ho < Ho && wo < Wo;
+                const int64_t o = ((((int64_t)b * Ho + min(ho, Ho - 1)) * Wo + min(wo, Wo - 1)) * cpr + cc) * VEC;
+                dv[di][dj] = vload<T>(dpool + o);
+                iv[di][dj] = *reinterpret_cast<const IdxT*>(idx + o);
+            }
+    }
+    // gradient of input pixel (2i + a, 2j + c): the windows whose argmax is this pixel (the arithmetic of maxpool_bwd_kernel)
+    __device__ __forceinline__ void gather(int a, int c, float (&acc)[VEC]) const {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+#pragma unroll
+        for (int di = 0; di < 2; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                if (di > a || dj > c || !ok[di][dj]) continue;
+                const int r = a ? 2 - 2 * di : 1, q = c ? 2 - 2 * dj : 1;      // hi = 2 ho - 1 + r
+#pragma unroll
+                for (int v = 0; v < VEC; ++v)
+                    if ((int)((iv[di][dj] >> (8 * v)) & 0xff) == r * 3 + q) acc[v] += dv[di][dj].get(v);
+            }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = to_f32(from_f32<T>(acc[v]));     // the value capmi_maxpool3x3s2_bwd would have stored
+    }
+};
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x,
+                                                                 const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 float* acc_rows, int B, int Hi, int Wi, int C, int Ho, int Wo, int rows_per_block) {
+    constexpr int VEC = Vec<T>::N;
+    __shared__ float part[256 * VEC];
+    const int cpr = C / VEC, Wb = (Wi + 1) >> 1, Hb = (Hi + 1) >> 1;
+    const int tid = threadIdx.x, t = blockIdx.x * 256 + tid;
+    const int j = t / cpr, cc = t - j * cpr;
+    const bool active = j < Wb;
+    ColLayout L;
+    L.cpc = cpr; L.rp = 256 / cpr; L.rows_per_block = 0;
+    float a1[VEC], a2[VEC], mu[VEC], is[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { a1[v] = 0.f; a2[v] = 0.f; mu[v] = mean[cc * VEC + v]; is[v] = invstd[cc * VEC + v]; }
+    const int r_end = min(B * Hb, (int)(blockIdx.y + 1) * rows_per_block);
+    if (active)
+        for (int r = blockIdx.y * rows_per_block; r < r_end; ++r) {
+            const int b = r / Hb, i = r - b * Hb;
+            PoolWin<T> w;
+            w.load(dpool, idx, b, i, j, cc, cpr, Ho, Wo);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int hi = 2 * i + a, wi = 2 * j + c;
+                    if (hi >= Hi || wi >= Wi) continue;
+                    const int64_t o = ((((int64_t)b * Hi + hi) * Wi + wi) * cpr + cc) * VEC;
+                    Vec<T> xv = vload<T>(x + o), yv = vload<T>(y + o);
+                    float g[VEC];
+                    w.gather(a, c, g);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const float dz = g[v] * act_grad_from_out(yv.get(v), ACT);
+                        a1[v] += dz;
+                        a2[v] += dz * (xv.get(v) - mu[v]) * is[v];
+                    }
+                }
+        }
+    block_col_reduce<VEC>(part, a1, tid % cpr, tid / cpr, L, true);
+    block_col_reduce<VEC>(part, a2, tid % cpr, tid / cpr, L, true);
+    // block totals -> one f32 atomic per column into the accumulator row of this block (capmi_bn_bwd_reduce_spread's layout)
+    __syncthreads();
+    if (tid / cpr == 0) {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { part[(tid % cpr) * VEC + v] = a1[v]; part[C + (tid % cpr) * VEC + v] = a2[v]; }
+    }
+    __syncthreads();
+    float* row = acc_rows + (int64_t)((blockIdx.y * gridDim.x + blockIdx.x) & (BN_SPREAD_ROWS - 1)) * 2 * C;
+    for (int e = tid; e < 2 * C; e += 256) __hip_atomic_fetch_add(row + e, part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One workgroup = rows_per_block rows of 2 x 2 blocks: the per-channel constants (16-byte loads, the accumulator rows among
+// them) are formed once per thread behind the first row's loads, as in bn_bwd_apply_kernel.
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x,
+                                                                const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                const float* __restrict__ scale, const float* __restrict__ acc_rows, float* red_out, T* dx,
+                                                                int B, int Hi, int Wi, int C, int Ho, int Wo, int rows_per_block, float inv_m) {
+    constexpr int VEC = Vec<T>::N;
+    const int cpr = C / VEC, Wb = (Wi + 1) >> 1, Hb = (Hi + 1) >> 1;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int j = t / cpr, cc = t - j * cpr;
+    if (j >= Wb) return;
+    f32x4 isv[VEC / 4], scv[VEC / 4], muv[VEC / 4], t0[BN_SPREAD_ROWS][VEC / 4], t1[BN_SPREAD_ROWS][VEC / 4];
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+        const int ch = cc * VEC + 4 * q;
+        isv[q] = *reinterpret_cast<const f32x4*>(invstd + ch);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) scv[q][e] = scale[ch + e];       // a view into the flat parameter vector: any 4-byte alignment
+        muv[q] = *reinterpret_cast<const f32x4*>(mean + ch);
+#pragma unroll
+        for (int r = 0; r < BN_SPREAD_ROWS; ++r) {
+            t0[r][q] = *reinterpret_cast<const f32x4*>(acc_rows + (int64_t)r * 2 * C + ch);
+            t1[r][q] = *reinterpret_cast<const f32x4*>(acc_rows + (int64_t)r * 2 * C + C + ch);
+        }
+    }
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(B * Hb, r_begin + rows_per_block);
+    PoolWin<T> w;
+    Vec<T> xv[2][2], yv[2][2];
+    auto load_row = [&](int r) {
+        const int b = r / Hb, i = r - b * Hb;
+        w.load(dpool, idx, b, i, j, cc, cpr, Ho, Wo);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int hi = min(2 * i + a, Hi - 1), wi = min(2 * j + c, Wi - 1);      // clamped: the store below is guarded
+                const int64_t o = ((((int64_t)b * Hi + hi) * Wi + wi) * cpr + cc) * VEC;
+                xv[a][c] = vload<T>(x + o);
+                yv[a][c] = vload<T>(y + o);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    float k1[VEC], c2[VEC], m0[VEC], mu[VEC];
+    auto store_row = [&](int r) {
+        const int b = r / Hb, i = r - b * Hb;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int hi = 2 * i + a, wi = 2 * j + c;
+                if (hi >= Hi || wi >= Wi) continue;
+                const int64_t o = ((((int64_t)b * Hi + hi) * Wi + wi) * cpr + cc) * VEC;
+                Vec<T> ov;
+                float g[VEC];
+                w.gather(a, c, g);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float dz = g[v] * act_grad_from_out(yv[a][c].get(v), ACT);
+                    ov.set(v, k1[v] * ((dz - m0[v]) - (xv[a][c].get(v) - mu[v]) * c2[v]));
+                }
+                vstore<T>(dx + o, ov);
+            }
+    };
+    if (r_begin < r_end) load_row(r_begin);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+        for (int q = 0; q < BN_SPREAD_ROWS; ++q) { r0 += t0[q][v / 4][v % 4]; r1 += t1[q][v / 4][v % 4]; }
+        const float is_ = isv[v / 4][v % 4];
+        mu[v] = muv[v / 4][v % 4];
+        k1[v] = scv[v / 4][v % 4] * is_;
+        c2[v] = is_ * r1 * inv_m;
+        m0[v] = r0 * inv_m;
+        if (blockIdx.y == 0 && j == 0) { red_out[cc * VEC + v] += r0; red_out[C + cc * VEC + v] += r1; }      // one writer per channel
+    }
+    for (int r = r_begin; r < r_end; ++r) {
+        if (r != r_begin) load_row(r);
+        store_row(r);
+    }
+}
+
+extern "C" int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int B, int Hi, int Wi, int C, int Ho, int Wo, int dtype, void* stream);
+
+/* capmi_maxpool3x3s2_bwd + capmi_bn_bwd_reduce_spread / capmi_bn_bwd_apply_spread of the layer that feeds the pool, without
+ * materialising the pool's input gradient (see above).  dpool [B,Ho,Wo,C]: gradient of the pool's output; idx: the forward
+ * pass's argmax map; x / y: the layer's conv output and activated output [B,Hi,Wi,C]; acc: the layer's accumulator rows
+ * (zeroed once per step).  dy_scratch [B,Hi,Wi,C] is written only in deterministic mode, where the pair IS the three-launch
+ * path (capmi_maxpool3x3s2_bwd, then the two-stage reduction through ws / red). */
+extern "C" int capmi_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* saved_mean,
+                                        const float* saved_invstd, float* ws, float* red, float* acc, void* dy_scratch, int B, int Hi, int Wi, int C,
+                                        int Ho, int Wo, int act, int dtype, void* stream) {
+    CAPMI_CHECK(dpool && idx && x && y && saved_mean && saved_invstd && acc && dy_scratch, "capmi_bn_bwd_reduce_pool: null pointer");
+    CAPMI_CHECK(act == CAPMI_ACT_RELU || act == CAPMI_ACT_RELU6, "capmi_bn_bwd_reduce_pool: the pooled layer's activation must be relu or relu6");
+    const int M = B * Hi * Wi;
+    if (capmi_deterministic()) {
+        if (capmi_maxpool3x3s2_bwd(dpool, idx, dy_scratch, B, Hi, Wi, C, Ho, Wo, dtype, stream)) return 1;
+        return capmi_bn_bwd_reduce(dy_scratch, x, y, saved_mean, saved_invstd, ws, red, M, C, act, dtype, stream);
+    }
+    CAPMI_DISPATCH(dtype, "capmi_bn_bwd_reduce_pool", {
+        constexpr int VEC = Vec<T>::N;
+        CAPMI_CHECK(C % VEC == 0 && 256 % (C / VEC) == 0 && 2 * C <= 256 * VEC, "capmi_bn_bwd_reduce_pool: C=%d unsupported (C / %d must divide 256)", C, VEC);
+        const int cpr = C / VEC, Wb = (Wi + 1) / 2, Hb = (Hi + 1) / 2;
+        const int gx = cdiv(Wb * cpr, 256);
+        static const int wgs = getenv("CAPMI_POOL_WGS") ? atoi(getenv("CAPMI_POOL_WGS")) : 1024;      // experiment knob
+        int rpb = cdiv((int64_t)B * Hb * gx, wgs);         // ~4 workgroups per CU (256 adds per accumulator address)
+        if (rpb < 1) rpb = 1;
+        const dim3 grid(gx, cdiv(B * Hb, rpb));
+        if (act == CAPMI_ACT_RELU) hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T, CAPMI_ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, acc, B, Hi, Wi, C, Ho, Wo, rpb);
+        else hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T, CAPMI_ACT_RELU6>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, acc, B, Hi, Wi, C, Ho, Wo, rpb);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bn_bwd_reduce_pool");
+    return 0;
+}
+extern "C" int capmi_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* saved_mean,
+                                       const float* saved_invstd, const float* scale, float* red, const float* acc, const void* dy_scratch, void* dx,
+                                       int B, int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream) {
+    CAPMI_CHECK(dpool && idx && x && y && saved_mean && saved_invstd && scale && red && acc && dy_scratch && dx, "capmi_bn_bwd_apply_pool: null pointer");
+    CAPMI_CHECK(act == CAPMI_ACT_RELU || act == CAPMI_ACT_RELU6, "capmi_bn_bwd_apply_pool: the pooled layer's activation must be relu or relu6");
+    const int M = B * Hi * Wi;
+    if (capmi_deterministic())      // dy_scratch holds the pool's input gradient (capmi_bn_bwd_reduce_pool wrote it)
+        return capmi_bn_bwd_apply(dy_scratch, x, y, saved_mean, saved_invstd, scale, red, dx, 0, nullptr, 0, M, C, act, dtype, stream);
+    CAPMI_DISPATCH(dtype, "capmi_bn_bwd_apply_pool", {
+        constexpr int VEC = Vec<T>::N;
+        CAPMI_CHECK(C % VEC == 0 && 256 % (C / VEC) == 0, "capmi_bn_bwd_apply_pool: C=%d unsupported", C);
+        CAPMI_CHECK(((uintptr_t)acc | (uintptr_t)saved_mean | (uintptr_t)saved_invstd) % 16 == 0, "capmi_bn_bwd_apply_pool: acc8 / saved_mean / saved_invstd must be 16-byte aligned");
+        const int cpr = C / VEC, Wb = (Wi + 1) / 2, Hb = (Hi + 1) / 2;
+        const int gx = cdiv(Wb * cpr, 256);
+        int rpb = cdiv((int64_t)B * Hb * gx, 4096);          // ~16 workgroups per CU, a few rows each
+        if (rpb < 1) rpb = 1;
+        const dim3 grid(gx, cdiv(B * Hb, rpb));
+        if (act == CAPMI_ACT_RELU) hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T, CAPMI_ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, acc, red, (T*)dx, B, Hi, Wi, C, Ho, Wo, rpb, 1.f / (float)M);
+        else hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T, CAPMI_ACT_RELU6>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, acc, red, (T*)dx, B, Hi, Wi, C, Ho, Wo, rpb, 1.f / (float)M);
+    });
+    CAPMI_LAUNCH_CHECK("capmi_bn_bwd_apply_pool");
+    return 0;
 }

@@ -2470,10 +2470,11 @@ __device__ __forceinline__ void tr_reads_done() {
 // PIPE: fragments double-buffered in registers -- iteration t issues the DMA of stage t + NST (into the slot whose
 //       fragments were just consumed into registers), reads the fragments of stage t + 1 and multiplies stage t: the LDS
 //       read latency sits under the MFMAs and a DMA has NST - 1 iterations to land.
-template <int ABL, int NST = 2, int KS = 1, bool PIPE = false>
+template <int ABL, int NST = 2, int KS = 1, bool PIPE = false, int RM = 64>
 __global__ __launch_bounds__(512, (KS == 2 || PIPE) ? 1 : 2) void igemm_tn_glds_kernel(WGradArgs a) {
     typedef bf16 T;
-    constexpr int BNO = 128, BKO = 128, RM = 64;              // 64 reduction rows per stage: two MFMA k-steps per barrier
+    constexpr int BNO = 128, BKO = 128;                       // RM = 64 reduction rows per stage: two MFMA k-steps per barrier
+    static_assert(RM == 32 || RM == 64, "a stage is one or two 32-row MFMA k-steps");
     constexpr int OPB = RM * 256, STB = 2 * OPB;            // bytes per operand tile / per stage
     constexpr int TN_ = 4, TK_ = KS == 2 ? 4 : 2;
     static_assert(KS == 1 || NST * STB >= BNO * BKO * 4, "the accumulator exchange needs one f32 tile inside the ring");
@@ -2737,7 +2738,17 @@ static int launch_tn(WGradArgs& a, float* ws, long long ws_bytes, hipStream_t st
                     (long long)splits * a.Np * a.Kp * 4);
         a.slab = ws;
     }
-    if constexpr (sizeof(T) == 2 && BNO == 128) hipLaunchKernelGGL(igemm_tn_glds_kernel<0>, dim3(tiles * splits), dim3(512), 0, st, a);
+    if constexpr (sizeof(T) == 2 && BNO == 128) {
+        // The LDS footprint of this kernel decides how many workgroups of the MAIN lane fit next to it on a CU (160 KB): beside the
+        // 64 KB ring of two 64-row stages the 36 KB forward / data-gradient tiles run 2 per CU instead of 4 and the 96 KB k-group
+        // kernels not at all; beside 48 KB (three 32-row stages) 3 per CU resp. 1.  Alone the 48 KB form is a few per cent
+        // slower, in the step it is worth 0.10 ms (8.84 -> 8.74, A/B on one box); 32 KB (two 32-row stages) starves the kernel
+        // itself (+0.2 ms).  CAPMI_TN_SMALL = 0 / 1 / 2 selects 64 / 32 / 48 KB (lesson 47).
+        static const int small = getenv("CAPMI_TN_SMALL") ? atoi(getenv("CAPMI_TN_SMALL")) : 2;
+        if (small == 1) hipLaunchKernelGGL((igemm_tn_glds_kernel<0, 2, 1, false, 32>), dim3(tiles * splits), dim3(512), 0, st, a);
+        else if (small == 2) hipLaunchKernelGGL((igemm_tn_glds_kernel<0, 3, 1, false, 32>), dim3(tiles * splits), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(igemm_tn_glds_kernel<0>, dim3(tiles * splits), dim3(512), 0, st, a);
+    }
     else hipLaunchKernelGGL((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles * splits), dim3(256), 0, st, a);
     if (use_slab)
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.Np / 32, a.Kp / 32), dim3(256), 0, st, ws, splits, a.Np, a.Kp, a.dw, a.N, a.K, a.lddw);

@@ -79,6 +79,8 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_bn_bwd_apply),
     CAPMI_ENTRY(capmi_bn_bwd_reduce_spread),
     CAPMI_ENTRY(capmi_bn_bwd_apply_spread),
+    CAPMI_ENTRY(capmi_bn_bwd_reduce_pool),
+    CAPMI_ENTRY(capmi_bn_bwd_apply_pool),
     CAPMI_ENTRY(capmi_add_act),
     CAPMI_ENTRY(capmi_act_bwd),
     CAPMI_ENTRY(capmi_mean_rows),

@@ -151,6 +151,8 @@ class EncoderRunner:
         # capmi_bn_bwd_reduce_spread: eight accumulator rows [8][2C] per batch-norm layer, one buffer for all of them (zeroed by
         # ONE fill per step, model._compile_train); CAPMI_BN_SPREAD=0 keeps the two-stage reduction
         self.bn_spread = need_backward and os.environ.get('CAPMI_BN_SPREAD', '1') != '0'
+        # max-pool backward gathered inside the producer's batch-norm backward (capmi_bn_bwd_reduce_pool); needs the accumulator rows
+        self.pool_fuse = self.bn_spread and os.environ.get('CAPMI_POOL_FUSE', '1') != '0'
         self.bn_acc, off = {}, 0
         for op in enc.ops:
             if isinstance(op, arch.ConvBN) and id(op) not in self.skipped:
@@ -459,6 +461,11 @@ class EncoderRunner:
                 f = self.fused_add.get(o.dst)
                 conv_of_out[f.dst if f else o.dst] = o
         reduced = {}                    # id(ConvBN) -> (workspace, parts): BN backward sums already taken by a dgrad epilogue
+        pool_fused = {}                 # tensor id -> the MaxPool whose backward its producer's batch-norm backward carries
+
+        def consumers_of(t):
+            return sum(1 for o in self.enc.ops if id(o) not in self.skipped
+                       and (t in (o.a, o.b) if isinstance(o, arch.Add) else o.src == t))
         ws_busy = [None, None]
 
         def bnred_targets(t):
@@ -510,6 +517,7 @@ class EncoderRunner:
                 dy = grad_buf(out_id)
                 y = self.act[out_id]
                 red = st.gview(op.name + '_bn_offset')        # [d offset | d scale] adjacent in the flat buffer
+                pool = None
                 assert c % 8 == 0 and st.entries[op.name + '_bn_scale'].offset == st.entries[op.name + '_bn_offset'].offset + c
                 if id(op) in reduced:
                     slot, parts = reduced.pop(id(op))
@@ -517,6 +525,18 @@ class EncoderRunner:
                     plan.add('capmi_bn_bwd_reduce_final', _p(self.red_ws[slot]), parts, c, _p(red))
                     ws_busy[slot] = None
                     spread = None
+                elif out_id in pool_fused:
+                    # the layer feeds a max pool and nothing else: both kernels gather the pool's input gradient from the pooled
+                    # one and the argmax map (capmi_bn_bwd_reduce_pool) -- it is never written
+                    pool = pool_fused.pop(out_id)
+                    spread = None
+                    acc = self.bn_acc_all.data_ptr() + 4 * self.bn_acc[op.dst]
+                    pho, pwo, _ = self.shape[pool.dst]
+                    pargs = (B, ho, wo, c, pho, pwo, act, code)
+                    plan.add('capmi_bn_bwd_reduce_pool', _p(self.grad[pool.dst]), _p(self.pool_idx[pool.dst]), _p(raw), _p(y), _p(bn['mean']),
+                             _p(bn['invstd']), _p(self.bwd_ws), _p(red), acc, _p(self.grad[out_id]), *pargs)
+                    plan.add('capmi_bn_bwd_apply_pool', _p(self.grad[pool.dst]), _p(self.pool_idx[pool.dst]), _p(raw), _p(y), _p(bn['mean']),
+                             _p(bn['invstd']), _p(st.view(op.name + '_bn_scale')), _p(red), acc, _p(self.grad[out_id]), _p(draw), *pargs)
                 elif self.bn_spread:
                     spread = self.bn_acc_all.data_ptr() + 4 * self.bn_acc[op.dst]
                     plan.add('capmi_bn_bwd_reduce_spread', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
@@ -537,7 +557,9 @@ class EncoderRunner:
                         dres = self.grad[fa.a]
                         dres_acc = 1 if fa.a in written else 0
                         written.add(fa.a)
-                if spread is not None:
+                if pool is not None:
+                    pass
+                elif spread is not None:
                     plan.add('capmi_bn_bwd_apply_spread', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
                              _p(st.view(op.name + '_bn_scale')), _p(red), spread, _p(draw), 0, _p(dres), dres_acc, M, c, act, code, lane=ln)
                 else:
@@ -656,6 +678,15 @@ class EncoderRunner:
                 ho, wo, _ = self.shape[op.dst]
                 assert op.src not in written and op.src not in pending
                 materialize(op.dst)
+                prod = conv_of_out.get(op.src)
+                if (self.pool_fuse and prod is not None and prod.dst == op.src and id(prod) not in early and id(prod) not in reduced
+                        and tensor_act.get(op.src) in ('relu', 'relu6') and op.dst in written and consumers_of(op.src) == 1
+                        and 256 % (c // (8 if code == 1 else 4)) == 0):
+                    pool_fused[op.src] = op          # the producer's batch-norm backward gathers from grad[op.dst] itself
+                    written.add(op.src)
+                    done.add(id(op))
+                    flush_marks()
+                    continue
                 plan.add('capmi_maxpool3x3s2_bwd', _p(self.grad[op.dst]), _p(self.pool_idx[op.dst]), _p(self.grad[op.src]), B, hi, wi, c, ho, wo, code)
                 written.add(op.src)
             done.add(id(op))

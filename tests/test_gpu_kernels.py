@@ -485,6 +485,74 @@ def test_batch_norm_chain(dtype, act, res):
         _lib.set_deterministic(prev)
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_batch_norm_backward_gathered_from_a_max_pool_gradient(dtype):
+    """capmi_bn_bwd_reduce_pool / capmi_bn_bwd_apply_pool == capmi_maxpool3x3s2_bwd + the batch-norm backward pair on the
+    materialised gradient (oracle chain: ops.maxpool3x3s2_bwd -> ops.batch_norm_bwd behind a relu), for even / odd extents."""
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(11)
+    f32 = torch.float32
+    for B, C, H, W in [(2, 64, 16, 16), (3, 32, 9, 13), (1, 16, 7, 8), (2, 64, 12, 11)]:
+        M = B * H * W
+        x = rnd(rng.standard_normal((B, C, H, W)) * 1.5 + 0.3, dtype)
+        scale = (1.0 + 0.2 * rng.standard_normal(C)).astype(np.float32)
+        offset = (0.2 * rng.standard_normal(C)).astype(np.float32)
+        x64 = x.astype(np.float64)
+        out, saved, _ = O.batch_norm_fwd(x64, scale.astype(np.float64), offset.astype(np.float64), np.zeros(C), np.ones(C))
+        yact = rnd(np.maximum(out, 0.0), dtype)
+        pooled, idx = O.maxpool3x3s2_fwd(yact)
+        Ho, Wo = pooled.shape[2:]
+        dpool = rnd(rng.standard_normal(pooled.shape), dtype)
+        mean = dev(x64.mean((0, 2, 3)), f32)
+        invstd = dev(saved[1], f32)
+        X, Y = dev(_nhwc(x), tdt[dtype]), dev(_nhwc(yact), tdt[dtype])
+        DP = dev(_nhwc(dpool), tdt[dtype])
+        IDX = dev(_nhwc(idx), torch.uint8)
+        SC = dev(scale, f32)
+        ac = _lib.ACT_CODES['relu']
+        # reference: three launches on the materialised gradient
+        DYP = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+        _lib.call('capmi_maxpool3x3s2_bwd', p(DP), p(IDX), p(DYP), B, H, W, C, Ho, Wo, code[dtype], stream())
+        red = torch.zeros(2 * C, dtype=f32, device=DEV)
+        bws = torch.zeros(_lib.lib().capmi_bn_bwd_ws_floats(M, C, code[dtype]), dtype=f32, device=DEV)
+        DX = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+        _lib.call('capmi_bn_bwd_reduce', p(DYP), p(X), p(Y), p(mean), p(invstd), p(bws), p(red), M, C, ac, code[dtype], stream())
+        _lib.call('capmi_bn_bwd_apply', p(DYP), p(X), p(Y), p(mean), p(invstd), p(SC), p(red), p(DX), 0, None, 0, M, C, ac, code[dtype], stream())
+        # oracle chain on the same operands
+        dyp = O.maxpool3x3s2_bwd(dpool, idx, x.shape)
+        dz = dyp.astype(np.float64) * (yact > 0)
+        dx_o, _, _ = O.batch_norm_bwd(dz, saved, scale.astype(np.float64))
+        check(host(DX), _nhwc(dx_o), dtype, name='pool + bn dx (three launches)')
+        # the gathered pair
+        acc8 = torch.zeros(16 * C, dtype=f32, device=DEV)
+        red2 = torch.zeros(2 * C, dtype=f32, device=DEV)
+        scratch = torch.full((B, H, W, C), float('nan'), dtype=tdt[dtype], device=DEV)
+        DX2 = torch.full((B, H, W, C), float('nan'), dtype=tdt[dtype], device=DEV)
+        _KEEP.extend([DYP, red, bws, DX, acc8, red2, scratch, DX2])
+        args = (B, H, W, C, Ho, Wo, ac, code[dtype], stream())
+        _lib.call('capmi_bn_bwd_reduce_pool', p(DP), p(IDX), p(X), p(Y), p(mean), p(invstd), p(bws), p(red2), p(acc8), p(scratch), *args)
+        _lib.call('capmi_bn_bwd_apply_pool', p(DP), p(IDX), p(X), p(Y), p(mean), p(invstd), p(SC), p(red2), p(acc8), p(scratch), p(DX2), *args)
+        torch.cuda.synchronize()
+        sc_ = float(np.abs(dz).sum((0, 2, 3)).max())
+        assert torch.allclose(red2, red, rtol=1e-5, atol=1e-5 * sc_), float((red2 - red).abs().max())
+        assert bool(torch.isnan(scratch.float()).all())           # the pool's input gradient is never written
+        check(host(DX2), _nhwc(dx_o), dtype, name='pool + bn dx (gathered)')
+        assert float((DX2.float() - DX.float()).abs().max()) <= (1e-4 if dtype == 'f32' else 2 ** -6) * max(1.0, float(DX.float().abs().max()))
+        # deterministic mode: the pair IS the three-launch path, bit for bit
+        prev = _lib.set_deterministic(True)
+        try:
+            red3 = torch.zeros(2 * C, dtype=f32, device=DEV)
+            DX3 = torch.zeros((B, H, W, C), dtype=tdt[dtype], device=DEV)
+            acc8.zero_()
+            _KEEP.extend([red3, DX3])
+            _lib.call('capmi_bn_bwd_reduce_pool', p(DP), p(IDX), p(X), p(Y), p(mean), p(invstd), p(bws), p(red3), p(acc8), p(scratch), *args)
+            _lib.call('capmi_bn_bwd_apply_pool', p(DP), p(IDX), p(X), p(Y), p(mean), p(invstd), p(SC), p(red3), p(acc8), p(scratch), p(DX3), *args)
+            torch.cuda.synchronize()
+            assert torch.equal(red3, red) and torch.equal(DX3, DX) and torch.equal(scratch, DYP) and not bool(acc8.any())
+        finally:
+            _lib.set_deterministic(prev)
+
+
 def test_batch_norm_statistics_no_cancellation():
     """mean >> std: a single-pass E[x^2]-E[x]^2 in f32 loses the variance entirely here."""
     _lib, tdt, code = _env()
