@@ -9,6 +9,14 @@ template <> __device__ __forceinline__ f32x4 adam_load4<bf16>(const bf16* g, int
     const bf16x4 v = reinterpret_cast<const bf16x4*>(g)[i];
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
+// Grid of the bulk updates (>= 2^21 16-byte chunks: the optimizer / shadow refresh of most of the model, which the engine runs
+// on the side lane UNDER the backward pass): experiment knob CAPMI_BULK_WGS caps it so that the main lane's kernels find free
+// slots next to it.
+static inline int bulk_grid(int64_t chunks, int64_t elems) {
+    static const int cap = getenv("CAPMI_BULK_WGS") ? atoi(getenv("CAPMI_BULK_WGS")) : 0;
+    const int g = ew_grid(chunks);
+    return (cap > 0 && elems >= (1ll << 23) && g > cap) ? cap : g;
+}
 template <typename G>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                    int64_t n, float lr_t, float b1, float b2, float eps, float clip, float gscale) {
@@ -42,7 +50,7 @@ extern "C" int capmi_adam(float* p, const float* g, float* m, float* v, int64_t 
     CAPMI_CHECK(p && g && m && v, "capmi_adam: null pointer");
     CAPMI_CHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0, "capmi_adam: buffers must be 16-byte aligned");
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(adam_kernel<float>, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, b1, b2, eps, clip, grad_scale);
+    hipLaunchKernelGGL(adam_kernel<float>, dim3(bulk_grid(n / 4 + 1, n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, b1, b2, eps, clip, grad_scale);
     CAPMI_LAUNCH_CHECK("capmi_adam");
     return 0;
 }
@@ -62,9 +70,26 @@ template <typename T>
 __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, T* dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = from_f32<T>(src[i]);
 }
+// 8 elements per thread and iteration: two 16-byte loads, one 16-byte (bf16) store; the tail goes through the scalar form
+__global__ __launch_bounds__(256) void cast8_kernel(const float* __restrict__ src, bf16* dst, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { o[k] = (bf16)a[k]; o[4 + k] = (bf16)b[k]; }
+        reinterpret_cast<bf16x8*>(dst)[i] = o;
+    }
+}
 extern "C" int capmi_cast(const float* src, void* dst, int64_t n, int dtype, void* stream) {
     CAPMI_CHECK(src && dst, "capmi_cast: null pointer");
     if (n <= 0) return 0;
+    if (dtype == CAPMI_BF16 && n >= 4096 && ((uintptr_t)src | (uintptr_t)dst) % 16 == 0) {
+        const int64_t n8 = n / 8;
+        hipLaunchKernelGGL(cast8_kernel, dim3(bulk_grid(n8, n)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n8);
+        if (n > n8 * 8) hipLaunchKernelGGL(cast_kernel<bf16>, dim3(1), dim3(256), 0, (hipStream_t)stream, src + n8 * 8, (bf16*)dst + n8 * 8, n - n8 * 8);
+        CAPMI_LAUNCH_CHECK("capmi_cast");
+        return 0;
+    }
     CAPMI_DISPATCH(dtype, "capmi_cast", {
         hipLaunchKernelGGL(cast_kernel<T>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, src, (T*)dst, n);
     });

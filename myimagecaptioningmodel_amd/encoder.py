@@ -187,6 +187,7 @@ class EncoderRunner:
         # step against 9.06 without, level 2 9.26 -- bit-identical results, no gain: the bn_apply launches it takes off the
         # forward chain (0.19 ms) come back as slower convolutions.  Kept as a tested alternate, off by default.
         inbn_level = int(os.environ.get('CAPMI_INBN', '0'))
+        inbn_max_rows = int(os.environ.get('CAPMI_INBN_MAXM', str(1 << 30)))
         if dtype_code == 1 and inbn_level > 0:
             for op in enc.ops:
                 if not isinstance(op, arch.ConvBN) or id(op) in self.skipped or op.groups != 1 or op.src == 0:
@@ -197,6 +198,9 @@ class EncoderRunner:
                 if op.src == self.out_id:
                     continue
                 kind = lib().capmi_igemm_nt_bnact_supported(self._conv_geom(op), op.cout, dtype_code)
+                ph, pw, _ = self.shape[P.dst]
+                if B * ph * pw > inbn_max_rows:      # experiment knob: only layers of at most this many pixels
+                    continue
                 if kind == 2 or (kind == 1 and inbn_level >= 2):
                     self.inbn[id(op)] = P
                     self.inbn_tensors.add(P.dst)
