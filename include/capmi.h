@@ -108,6 +108,19 @@ int capmi_igemm_nt_bnact(const void* x_raw, const void* w, void* y, const capmi_
                          const float* in_mean, const float* in_coef_a, const float* in_offset, int in_act,
                          float* stats, int dtype, void* stream);
 
+/* Convolution + batch-norm statistics + capmi_bn_finalize in ONE launch: conv2d -> batch_norm (train mode) of
+ * MobileNetV2.py:88-121 conv_bn_layer up to the saved mean / invstd / coef_a and the running statistics; follow with
+ * capmi_bn_apply.  = capmi_igemm_nt(x, w, y, g, N, ldw, ldy, NULL, NULL, 0, NULL, 0, stats, 0, 0, 0, dtype) followed by
+ * capmi_bn_finalize(stats, capmi_igemm_nt_stats_part_rows(M, N, K, dtype), M, N, ...), bit for bit: where the convolution's
+ * grid is small (bf16, <= 1024 workgroups, stream not capturing) every workgroup stores its statistics part write-through
+ * and counts itself in; the LAST one to arrive merges and finalizes (same f64 Chan fold, same fixed order), so the dependent
+ * ~10 us finalize launch behind the convolution disappears from the forward chain.  Elsewhere it IS the two calls.
+ * stats: the statistics workspace of the two-call form.  Library-owned arrival counters: the contract of capmi_bn_finalize
+ * (at most 127 later fused launches in flight next to an unfinished one on a device). */
+int capmi_igemm_nt_bnfin(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy, float* stats,
+                         const float* scale, float* run_mean, float* run_var, float momentum, float eps, float* saved_mean,
+                         float* saved_invstd, float* coef_a, int update_running, int dtype, void* stream);
+
 /* Plain product y[M][N] = x[M][K] . w[N][K]^T with a LONG reduction and a SMALL output (the tied projection's data
  * gradient, dR = dlogits . Emb: model_adaAttention_aic.py:25 backward, [T*B][V] x [V][E] -- 40 output tiles for 256 CUs):
  * K is split over workgroups into f32 slabs in ws (capmi_igemm_nt_splitk_ws_bytes(M, N, K, dtype) bytes; 0 = this shape

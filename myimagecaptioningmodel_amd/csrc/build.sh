@@ -10,7 +10,7 @@ flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$root/include -I$here $*"
 pids=()
 for f in capi plan igemm bn_ops encoder_ops decoder_ops optim; do
     src="$here/$f.hip"; obj="$objdir/$f.o"
-    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$here/common.h" -nt "$obj" ] || [ "$root/include/capmi.h" -nt "$obj" ]; then
+    if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$here/common.h" -nt "$obj" ] || [ "$here/bn_merge.h" -nt "$obj" ] || [ "$root/include/capmi.h" -nt "$obj" ]; then
         hipcc $flags -c "$src" -o "$obj" &
         pids+=($!)
     fi

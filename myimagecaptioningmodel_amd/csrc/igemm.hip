@@ -9,8 +9,10 @@
 // arrangement, register-staged double-buffered LDS tiles with 16-byte global loads; the output
 // tile goes back through LDS so that every global store is a full 16-byte chunk of a row.
 #include <stdlib.h>
+#include <atomic>
 
 #include "common.h"
+#include "bn_merge.h"
 
 // floor(n / d) as (n * ceil(2^40 / d)) >> 40, exact whenever n * d < 2^40 (checked by the launchers):
 // one 64-bit multiply instead of a ~40-instruction integer division.
@@ -55,6 +57,17 @@ struct IGemmArgs {
     const float* rmean[2];
     const float* rinv[2];
     float* rws[2];                   // [row block][2][N] partial sums
+    // batch-norm finalize by the last-arriving workgroup (capmi_igemm_nt_bnfin): fin_cnt != NULL switches it on
+    unsigned* fin_cnt;               // [tiles_n][fin_groups] group arrival counters, then [tiles_n] final counters (zero between launches)
+    float* fin_merged;               // [fin_groups][N][2] merged parts (two-level form only)
+    const float* fin_scale;
+    float* fin_run_mean;
+    float* fin_run_var;
+    float* fin_mean;
+    float* fin_invstd;
+    float* fin_a;
+    float fin_momentum, fin_eps;
+    int fin_update, fin_k, fin_groups;     // fin_k = parts per group (0: one level, the parts are finalized directly)
 #ifdef CAPMI_STAMPS
     unsigned long long* stamps;      // diagnostic build only: [workgroup][8] s_memtime stamps
 #endif
@@ -333,6 +346,73 @@ __device__ __forceinline__ void inbn_coef(const float* tab, int c0, f32x4 (&cf)[
     cf[5] = *reinterpret_cast<const f32x4*>(t + 2 * KC + 4);
 }
 
+// ------------------------------------------------------------------ batch-norm finalize by the last-arriving workgroup
+#ifndef CAPMI_FIN
+#define CAPMI_FIN 0         // the tail is compiled OUT by default (lesson 48: its mere presence in the shared epilogue costs every NT kernel ~0.04 ms per step); -DCAPMI_FIN=1 builds it in, capmi_igemm_nt_bnfin is the two calls otherwise
+#endif
+// capmi_igemm_nt_bnfin: the statistics merge + finalize of capmi_bn_finalize WITHOUT its launch (a dependent ~10 us kernel
+// behind every convolution of the forward chain).  Every workgroup has stored its part write-through; it drains its stores,
+// adds to the arrival counter of its group of fin_k row blocks (per column tile) and leaves -- unless it is the LAST of the
+// group: then it merges the group's parts (merge_parts, the fold order of bn_merge_kernel), stores the merged part
+// write-through and adds to the column tile's final counter; the last GROUP to arrive finalizes the tile's channels
+// (bn_finalize_body).  With <= 64 parts there is one level: the last workgroup of the column tile finalizes from the parts.
+// Nobody waits for anybody (the launch drains in any arrival order); counters are reset by their last arriver; the
+// arithmetic is capmi_bn_finalize's, bit for bit.  Runs on the 256 threads of the epilogue; sred: >= 6.2 KB of free LDS.
+template <int BM, int BN>
+__device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, float* sred) {
+    const int tid = threadIdx.x;
+    unsigned* flag = reinterpret_cast<unsigned*>(sred);
+    double (*red)[64] = reinterpret_cast<double (*)[64]>(sred + 16);
+    const int nparts = (a.M + BM - 1) / BM, p = m0 / BM, ntile = n0 / BN;
+    const int groups = a.fin_k > 0 ? a.fin_groups : 1;
+    const int grp = a.fin_k > 0 ? p / a.fin_k : 0;
+    const int gsize = a.fin_k > 0 ? min(a.fin_k, nparts - grp * a.fin_k) : nparts;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's write-through stores have left the chip's caches
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* c = a.fin_cnt + ntile * groups + grp;
+        const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == (unsigned)gsize - 1u;
+        if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
+        flag[0] = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!flag[0]) return;
+    if (a.fin_k > 0) {
+        const int p0 = grp * a.fin_k, p1 = min(nparts, p0 + a.fin_k);
+#pragma unroll
+        for (int cb = 0; cb < BN / 64; ++cb) {
+            const int c = n0 + cb * 64 + (tid & 63);
+            double mean, m2;
+            merge_parts<true>(a.stats, BM, a.M, a.N, c, p0, p1, red, &mean, &m2);
+            if ((tid >> 6) == 0 && c < a.N) {
+                const unsigned long long v = (unsigned long long)__builtin_bit_cast(unsigned, (float)mean) |
+                                             ((unsigned long long)__builtin_bit_cast(unsigned, (float)m2) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.fin_merged + ((int64_t)grp * a.N + c) * 2), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* c = a.fin_cnt + ((a.N + BN - 1) / BN) * groups + ntile;
+            const unsigned old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = old == (unsigned)groups - 1u;
+            if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag[0] = last ? 1u : 0u;
+        }
+        __syncthreads();
+        if (!flag[0]) return;
+    }
+    const float* src = a.fin_k > 0 ? a.fin_merged : a.stats;
+    const int rows = a.fin_k > 0 ? BM * a.fin_k : BM;
+#pragma unroll
+    for (int cb = 0; cb < BN / 64; ++cb) {
+        if (n0 + cb * 64 >= a.N) break;
+        bn_finalize_body<true>(src, rows, a.M, a.N, (n0 + cb * 64) / 64, a.fin_scale, a.fin_run_mean, a.fin_run_var, a.fin_momentum, a.fin_eps,
+                               a.fin_mean, a.fin_invstd, a.fin_a, a.fin_update, red);
+    }
+}
+
 // ------------------------------------------------------------------ shared epilogue of the tiled NT kernels
 template <typename T, int BM, int BN, int WMW, bool RED = false>
 __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred,
@@ -532,9 +612,15 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 m2 += sred[(w * BN + tid) * 2 + 1] + nw * d * d;
             }
             float* w = a.stats + ((int64_t)(m0 / BM) * a.N + n0 + tid) * 2;
-            w[0] = mean;
-            w[1] = m2;
+            if (CAPMI_FIN && a.fin_cnt) {        // write-through: another workgroup of this launch (the last to arrive) reads it
+                const unsigned long long v = (unsigned long long)__builtin_bit_cast(unsigned, mean) | ((unsigned long long)__builtin_bit_cast(unsigned, m2) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(w), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                w[0] = mean;
+                w[1] = m2;
+            }
         }
+        if (CAPMI_FIN && a.fin_cnt) nt_fin_tail<BM, BN>(a, m0, n0, sred);
     }
     if constexpr (RED)
     for (int q = 0; q < a.nred; ++q) {
@@ -1945,6 +2031,7 @@ static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const
                 "capmi_igemm_nt: bad output-scatter geometry");
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.bn_mean = nullptr; a.bn_a = nullptr; a.addend = addend; a.ysaved = ysaved; a.stats = stats;
     a.in_mean = nullptr; a.in_a = nullptr; a.in_off = nullptr; a.in_act = 0; a.ksplit = 1; a.kper = 0;
+    a.fin_cnt = nullptr; a.fin_merged = nullptr; a.fin_k = 0; a.fin_groups = 1;
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldw = ldw; a.ldy = ldy; a.ld_addend = ld_addend; a.ld_saved = ld_saved;
     a.g = *g; a.act = act; a.dact = dact; a.out_f32 = out_f32;
@@ -2110,6 +2197,73 @@ extern "C" int capmi_igemm_nt(const void* x, const void* w, void* y, const capmi
                               int ld_addend, const void* ysaved, int ld_saved, float* stats,
                               int act, int dact, int out_f32, int dtype, void* stream) {
     return igemm_nt_impl(x, w, y, g, N, ldw, ldy, bias, addend, ld_addend, ysaved, ld_saved, stats, act, dact, out_f32, 0, nullptr, dtype, stream);
+}
+
+// ------------------------------------------------------------------ convolution + statistics + finalize in one launch
+// Arrival counters of nt_fin_tail: a pool of 128 sets per DEVICE, handed out round-robin per launch and zero again when a
+// launch ends (the contract of capmi_bn_finalize's pool, capmi.h: at most 127 later fused launches in flight next to an
+// unfinished one; the engine joins its lanes at the end of every step).
+constexpr int FIN_SET = 1024;
+__device__ unsigned nt_fin_counters[128 * FIN_SET];
+static unsigned* next_fin_counters() {
+    constexpr int MAXDEV = 64;
+    static std::atomic<unsigned> next[MAXDEV];
+    static std::atomic<unsigned*> base[MAXDEV];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    unsigned* b = base[dev].load(std::memory_order_acquire);
+    if (!b) {
+        if (hipGetSymbolAddress((void**)&b, HIP_SYMBOL(nt_fin_counters)) != hipSuccess || !b) return nullptr;
+        base[dev].store(b, std::memory_order_release);
+    }
+    return b + (next[dev].fetch_add(1) % 128u) * FIN_SET;
+}
+
+/* capmi_igemm_nt with fused statistics (stats != NULL, no bias / addend / activation) followed by capmi_bn_finalize on those
+ * statistics -- conv2d -> batch_norm's statistics of MobileNetV2.py:88-121 conv_bn_layer (train mode) -- as ONE launch
+ * wherever the convolution's grid is small enough for the last-arriver tail to cost less than the dependent launch it
+ * replaces (nt_fin_tail; <= CAPMI_BNFIN_MAX_WGS workgroups, default 1024), and as the two calls otherwise (large grids, f32,
+ * captured streams).  Results are bit-identical either way.  stats: the workspace of the two-call form (parts + room for
+ * the merged parts, capmi.h). */
+extern "C" int capmi_igemm_nt_bnfin(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy, float* stats,
+                                    const float* scale, float* run_mean, float* run_var, float momentum, float eps, float* saved_mean,
+                                    float* saved_invstd, float* coef_a, int update_running, int dtype, void* stream) {
+    CAPMI_CHECK(stats && scale && saved_mean && saved_invstd && coef_a, "capmi_igemm_nt_bnfin: null pointer");
+    CAPMI_CHECK(!update_running || (run_mean && run_var), "capmi_igemm_nt_bnfin: running stats missing");
+    IGemmArgs a;
+    if (nt_prepare(a, x, w, y, g, N, ldw, ldy, nullptr, nullptr, 0, nullptr, 0, stats, 0, 0, 0, 0, nullptr, dtype)) return 1;
+    static const int max_wgs = getenv("CAPMI_BNFIN_MAX_WGS") ? atoi(getenv("CAPMI_BNFIN_MAX_WGS")) : 1024;
+    const NtCfg c = nt_cfg(a.M, N, a.K, dtype);
+    const int part_rows = c.bm;
+    bool fused = CAPMI_FIN && dtype == CAPMI_BF16 && max_wgs > 0 && !nt_uses_skinny(g, a.M, a.K, true, dtype);
+    int bn_tile = 0;
+    if (fused) {
+        // the column tile of the kernel nt_dispatch will pick (the counters are per column tile)
+        if (nt_halo3_ok(a, g, 0)) bn_tile = N <= 64 ? 64 : 128;
+        else if (c.wmw == 5) bn_tile = 64;
+        else if (c.bn == 128) bn_tile = 128;
+        else bn_tile = 64;
+        const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(N, bn_tile);
+        const int nparts = cdiv(a.M, part_rows);
+        const int k = nparts > 2 * CAPMI_BN_MERGE_GROUPS ? cdiv(nparts, N <= 128 ? 2 * CAPMI_BN_MERGE_GROUPS : CAPMI_BN_MERGE_GROUPS) : 0;
+        const int groups = k > 0 ? cdiv(nparts, k) : 1;
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cap);       // a captured launch would freeze its counter set into the graph
+        fused = tiles <= max_wgs && cdiv(N, bn_tile) * (groups + 1) <= FIN_SET && cap == hipStreamCaptureStatusNone;
+        if (fused) {
+            a.fin_cnt = next_fin_counters();
+            fused = a.fin_cnt != nullptr;
+            a.fin_k = k;
+            a.fin_groups = groups;
+            a.fin_merged = stats + (int64_t)nparts * N * 2;
+            a.fin_scale = scale; a.fin_run_mean = run_mean; a.fin_run_var = run_var; a.fin_mean = saved_mean; a.fin_invstd = saved_invstd;
+            a.fin_a = coef_a; a.fin_momentum = momentum; a.fin_eps = eps; a.fin_update = update_running;
+        }
+        if (!fused) a.fin_cnt = nullptr;
+    }
+    if (nt_dispatch(a, g, N, stats, 0, dtype, (hipStream_t)stream)) return 1;
+    if (fused) return 0;
+    return capmi_bn_finalize(stats, part_rows, a.M, N, scale, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, stream);
 }
 
 // ------------------------------------------------------------------ split-K over workgroups (deep K, few output tiles)

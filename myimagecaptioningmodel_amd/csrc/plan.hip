@@ -57,6 +57,7 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_igemm_nt_splitk),
     CAPMI_ENTRY(capmi_igemm_nt_bn),
     CAPMI_ENTRY(capmi_igemm_nt_bnact),
+    CAPMI_ENTRY(capmi_igemm_nt_bnfin),
     CAPMI_ENTRY(capmi_igemm_nt_bnred),
     CAPMI_ENTRY(capmi_igemm_tn_wgrad),
     CAPMI_ENTRY(capmi_colsum),

@@ -153,6 +153,10 @@ class EncoderRunner:
         self.bn_spread = need_backward and os.environ.get('CAPMI_BN_SPREAD', '1') != '0'
         # max-pool backward gathered inside the producer's batch-norm backward (capmi_bn_bwd_reduce_pool); needs the accumulator rows
         self.pool_fuse = self.bn_spread and os.environ.get('CAPMI_POOL_FUSE', '1') != '0'
+        # convolution + batch-norm statistics + finalize through ONE entry point (capmi_igemm_nt_bnfin: the last-arriving workgroup
+        # finalizes when the library is built with -DCAPMI_FIN=1).  Measured slower than the dependent launch it removes (DESIGN.md
+        # lesson 48): off by default.
+        self.bnfin = os.environ.get('CAPMI_BNFIN', '0') != '0'
         self.bn_acc, off = {}, 0
         for op in enc.ops:
             if isinstance(op, arch.ConvBN) and id(op) not in self.skipped:
@@ -294,6 +298,7 @@ class EncoderRunner:
                         plan.record(('fout', op.dst), 1)
                         side_out.add(op.dst)
                     continue
+                finalized = False
                 if op.src == 0:        # stem: space-to-depth of the NCHW feed, then an ordinary stride-1 implicit GEMM
                     plan.add('capmi_s2d_stem', _p(image), _p(self.s2d), B, op.cin, self.S, self.S, op.pad, self.stem_hb, self.stem_wb,
                              self.stem_cs, code)
@@ -313,14 +318,22 @@ class EncoderRunner:
                 else:
                     g = self._conv_geom(op)
                     K = op.k * op.k * op.cin
-                    plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
-                             None if is_test else _p(bn['stats']), 0, 0, 0, code, lane=ln)
+                    if not is_test and self.bnfin and M > self.fa_max_rows:
+                        # convolution + statistics + finalize as one launch (the last-arriving workgroup finalizes; large grids
+                        # run the two calls inside the entry point)
+                        plan.add('capmi_igemm_nt_bnfin', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, _p(bn['stats']),
+                                 _p(st.view(op.name + '_bn_scale')), _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']),
+                                 BN_MOMENTUM, BN_EPS, _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, code, lane=ln)
+                        finalized = True
+                    else:
+                        plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
+                                 None if is_test else _p(bn['stats']), 0, 0, 0, code, lane=ln)
                 if not is_test:
                     # small layers (stage 4 / 5 of a ResNet at batch 64): finalize inside the apply launch -- one dependent
                     # ~5 us kernel less on the forward chain; on big layers every one of thousands of apply workgroups would
                     # redo the merge (measured slower, capmi.h)
                     fa_fused = M <= self.fa_max_rows
-                    if not fa_fused:
+                    if not fa_fused and not finalized:
                         plan.add('capmi_bn_finalize', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')),
                                  _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS,
                                  _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, lane=ln)

@@ -667,6 +667,67 @@ def test_conv_with_inference_batch_norm_in_the_epilogue(dtype, B, C, H, W, Co, k
     assert float(d) <= tol * max(1.0, float(Y2.float().abs().max())), float(d)
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'f32'])
+@pytest.mark.parametrize('B,C,H,W,Co,k,s', [(64, 1024, 14, 14, 256, 1, 1),     # k-group kernel, 128 x 128 tiles, 98 parts: two levels
+                                             (64, 256, 14, 14, 256, 3, 1),      # halo kernel, 196 workgroups, two levels
+                                             (64, 256, 14, 14, 1024, 1, 1),     # 64 x 128 tiles, 1568 workgroups: the two-call form (grid too large)
+                                             (64, 512, 7, 7, 512, 3, 1),        # 7 x 7: 64 x 64 k-group tiles, 49 parts: ONE level
+                                             (64, 2048, 7, 7, 512, 1, 1),
+                                             (16, 512, 7, 7, 2048, 1, 1),       # 13 parts
+                                             (64, 1024, 14, 14, 2048, 1, 2),    # strided projection
+                                             (5, 96, 10, 7, 40, 1, 1),          # ragged M and N, one 64 x 64 column tile
+                                             (9, 32, 21, 19, 200, 3, 1),        # ragged N over two 128-wide column tiles, 57 parts
+                                             (33, 64, 14, 14, 72, 1, 1)])       # 102 parts of 64 rows, N = 72: two levels, ragged column tile
+def test_conv_statistics_finalize_in_one_launch(dtype, B, C, H, W, Co, k, s):
+    """capmi_igemm_nt_bnfin (conv2d -> batch_norm statistics of MobileNetV2.py:88-121, train mode): the last-arriving
+    workgroup of the convolution merges and finalizes.  Must equal capmi_igemm_nt + capmi_bn_finalize BIT FOR BIT -- output,
+    saved mean / invstd / coef_a and running statistics -- on three launches back to back (the arrival counters reset
+    themselves; a second 'last' workgroup would move the running statistics twice)."""
+    _lib, tdt, code = _env()
+    rng = np.random.RandomState(B + C + Co + k)
+    pad = 1 if k == 3 else 0
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    x = rnd(rng.standard_normal((B, H, W, C)) + 0.5, dtype)
+    w = rnd(rng.standard_normal((Co, k, k, C)) / np.sqrt(C * k * k), dtype)
+    f32 = torch.float32
+    X, Wk = dev(x, tdt[dtype]), dev(w, tdt[dtype])
+    g = _lib.ConvGeom(B, H, W, C, Ho, Wo, k, k, s, 1, pad, C)
+    M, K = B * Ho * Wo, k * k * C
+    pr = _lib.lib().capmi_igemm_nt_stats_part_rows(M, Co, K, code[dtype])
+    nparts = (M + pr - 1) // pr
+    SC = dev(rng.uniform(0.5, 1.5, Co), f32)
+    rm0, rv0 = rng.standard_normal(Co), rng.uniform(0.5, 2, Co)
+
+    def run(fused):
+        st = torch.zeros((nparts + 64, Co, 2), dtype=f32, device=DEV)
+        Y = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+        RM, RV = dev(rm0, f32), dev(rv0, f32)
+        outs = []
+        for _ in range(3):
+            o = [torch.zeros(Co, dtype=f32, device=DEV) for _ in range(3)]
+            outs.append(o)
+            if fused:
+                _lib.call('capmi_igemm_nt_bnfin', p(X), p(Wk), p(Y), g, Co, K, Co, p(st), p(SC), p(RM), p(RV), 0.9, 1e-5, p(o[0]), p(o[1]), p(o[2]), 1,
+                          code[dtype], stream())
+            else:
+                _lib.call('capmi_igemm_nt', p(X), p(Wk), p(Y), g, Co, K, Co, None, None, 0, None, 0, p(st), 0, 0, 0, code[dtype], stream())
+                _lib.call('capmi_bn_finalize', p(st), pr, M, Co, p(SC), p(RM), p(RV), 0.9, 1e-5, p(o[0]), p(o[1]), p(o[2]), 1, stream())
+        torch.cuda.synchronize()
+        _KEEP.extend([st, Y, RM, RV] + [t for o in outs for t in o])
+        return Y, st, RM, RV, outs
+
+    Yf, stf, RMf, RVf, of = run(True)
+    Yr, str_, RMr, RVr, orf = run(False)
+    assert torch.equal(Yf, Yr) and torch.equal(stf[:nparts], str_[:nparts])
+    for a_, b_ in zip(of, orf):
+        for q in range(3):
+            assert torch.equal(a_[q], b_[q]), ('launch output %d differs' % q, float((a_[q] - b_[q]).abs().max()))
+    assert torch.equal(RMf, RMr) and torch.equal(RVf, RVr)
+    # and against the plain statistics of the stored output
+    y64 = host(Yr).astype(np.float64).reshape(M, Co)
+    np.testing.assert_allclose(host(of[0][0]), y64.mean(0), rtol=0, atol=(2e-2 if dtype == 'bf16' else 1e-4))
+
+
 @pytest.mark.parametrize('B,C,H,W,Co,k,act', [(4, 64, 56, 56, 64, 3, 'relu'),      # halo kernel, 64 x 64 tiles, two channel chunks
                                                (8, 128, 28, 28, 128, 3, 'relu'),    # halo kernel, 128-wide tiles
                                                (3, 32, 9, 11, 48, 3, 'relu6'),      # ragged rows, one chunk, relu6
