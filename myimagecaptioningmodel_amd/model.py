@@ -405,13 +405,21 @@ class CaptionEngine:
         import ctypes
         st, bwd, cfg = self.store, prog['bwd'], self.cfg
         total = st.trainable_size
-        cut_idx, cut = None, total
-        for idx, opname in prog['marks']:
-            e = st.entries[opname + '_bn_scale']
-            off = e.offset + (int(e.kshape[0]) + 7) // 8 * 8
-            if off >= 0.9 * total and off < total:
-                cut_idx, cut = idx, off
-                break
+        # cut points (fractions of the flat parameter vector; the LAST one is the classic 90 % cut): the optimizer of the range
+        # between two cuts goes out as soon as its gradients are final.  One cut = one big update under the bandwidth-bound
+        # stage-3 / stage-2 backward; several = the decoder's and the deep stages' parameters are updated under the
+        # latency-bound stage-5 / stage-4 backward instead (CAPMI_OPT_CUTS, lesson 49).
+        fracs = [float(f) for f in os.environ.get('CAPMI_OPT_CUTS', '0.9').split(',') if f]
+        cuts = []                       # (plan index, flat offset), increasing
+        for frac in fracs:
+            for idx, opname in prog['marks']:
+                e = st.entries[opname + '_bn_scale']
+                off = e.offset + (int(e.kshape[0]) + 7) // 8 * 8
+                if off >= frac * total and off < total:
+                    if not cuts or (idx > cuts[-1][0] and off > cuts[-1][1]):
+                        cuts.append((idx, off))
+                    break
+        cut_idx, cut = cuts[-1] if cuts else (None, total)
         lrt = ctypes.c_float(0.0)
 
         def optimizer_range(plan, b, e, lane):
@@ -421,19 +429,25 @@ class CaptionEngine:
             self.plan_shadow(plan, b, e, lane)
 
         fused = Plan()
-        head = Plan()
-        head.calls, head._keep, head.has_lanes = bwd.calls[:cut_idx or 0], bwd._keep[:cut_idx or 0], bwd.has_lanes
-        tail = Plan()
-        tail.calls, tail._keep, tail.has_lanes = bwd.calls[cut_idx or 0:], bwd._keep[cut_idx or 0:], bwd.has_lanes
-        fused.extend(head)
+
+        def piece(i0, i1):
+            q = Plan()
+            q.calls, q._keep, q.has_lanes = bwd.calls[i0:i1], bwd._keep[i0:i1], bwd.has_lanes
+            return q
+
         if cut_idx is not None and bwd.has_lanes:
-            fused.record(('opt', 'head'), 0)
-            fused.wait(('opt', 'head'), 1)
-            optimizer_range(fused, 0, cut, 1)
-            shadow_range(fused, 0, cut, 1)
+            at, lo = 0, 0
+            for n, (idx, off) in enumerate(cuts):
+                fused.extend(piece(at, idx))
+                fused.record(('opt', 'head', n), 0)
+                fused.wait(('opt', 'head', n), 1)
+                optimizer_range(fused, lo, off, 1)
+                shadow_range(fused, lo, off, 1)
+                at, lo = idx, off
+            fused.extend(piece(at, None))
         else:
             cut = 0
-        fused.extend(tail)
+            fused.extend(piece(0, None))
         if bwd.has_lanes:
             fused.record(('opt', 'tail'), 1)            # the last weight gradient (side lane) is done
             fused.wait(('opt', 'tail'), 0)
