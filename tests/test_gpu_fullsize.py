@@ -292,7 +292,21 @@ def test_every_encoder_layer_in_situ_against_torch_matmul(monkeypatch, workload)
             blk = next(f.dst for f in enc.fused_add.values() if f.a == op.dst)
             dz = enc.grad[blk].float() * (enc.act[blk] > 0)
         else:
-            dz = enc.grad[out_id].float() * (enc.act[out_id] > 0) if act == 'relu' else enc.grad[out_id].float()
+            g_out = enc.grad[out_id].float()
+            pool = next((o for o in enc.enc.ops if isinstance(o, arch.MaxPool) and o.src == out_id), None)
+            if pool is not None and enc.pool_fuse:
+                # the layer feeds the max pool and the engine never materialises the pool's input gradient
+                # (capmi_bn_bwd_reduce_pool gathers it): rebuild it here from the pooled gradient and the argmax map
+                php, pwp, _ = enc.shape[pool.dst]
+                gp = enc.grad[pool.dst].float()
+                idx = enc.pool_idx[pool.dst].long()
+                bb, hh, ww, cc_ = torch.meshgrid(torch.arange(B, device='cuda'), torch.arange(php, device='cuda'),
+                                                 torch.arange(pwp, device='cuda'), torch.arange(co, device='cuda'), indexing='ij')
+                hi_, wi_ = 2 * hh - 1 + idx // 3, 2 * ww - 1 + idx % 3
+                flat = ((bb * ho + hi_) * wo + wi_) * co + cc_
+                g_out = torch.zeros(B * ho * wo * co, device='cuda').scatter_add_(0, flat.reshape(-1), gp.reshape(-1)).reshape(B, ho, wo, co)
+                g_out = g_out.to(torch.bfloat16).float()          # the value capmi_maxpool3x3s2_bwd would have stored
+            dz = g_out * (enc.act[out_id] > 0) if act == 'relu' else g_out
         xhat = (enc.raw[op.dst].float() - bn['mean']) * bn['invstd']
         s0 = dz.sum(dim=(0, 1, 2), dtype=torch.float64)
         s1 = (dz * xhat).sum(dim=(0, 1, 2), dtype=torch.float64)
