@@ -2098,6 +2098,9 @@ static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, b
 static bool nt_halo3_ok(const IGemmArgs& a, const capmi_conv_geom* g, int nred) {
     static const int mode = getenv("CAPMI_HALO3") ? atoi(getenv("CAPMI_HALO3")) : 1;      // 0: per-tap staging; 2 / 3: forward / data-gradient calls only
     if (mode == 0 || (mode == 2 && !a.stats) || (mode == 3 && a.stats)) return false;
+    // experiment knob: grids of at most this many 128 x 128 tiles take the k-group LDS-DMA kernel instead (8 waves per workgroup)
+    static const int min_tiles = getenv("CAPMI_HALO3_MINTILES") ? atoi(getenv("CAPMI_HALO3_MINTILES")) : 0;
+    if (min_tiles > 0 && (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) <= min_tiles) return false;
     return !nred && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->up == 1 && g->pad == 1 && g->Hi == g->Ho && g->Wi == g->Wo &&
            g->os <= 1 && g->Wi <= 56 && g->Wi * g->Hi > 64 && g->Cin % 32 == 0 && a.K == 9 * g->Cin && a.N >= 32;       // (7 x 7: the k-group kernel is faster)
 }
