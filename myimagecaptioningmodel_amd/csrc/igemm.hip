@@ -414,7 +414,12 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
 }
 
 // ------------------------------------------------------------------ shared epilogue of the tiled NT kernels
-template <typename T, int BM, int BN, int WMW, bool RED = false>
+// DENSE: the host guarantees N and every row pitch the epilogue touches are multiples of 8 (nt_dense): every lane stores whole
+// runs, and the element-wise store path -- HALF of each kernel's instructions, all of them unrolled copies that only ragged
+// shapes ever execute -- is compiled out.  The LDS-DMA kernel families are DENSE-only (ragged launches take the register-staged
+// kernel): the same step runs 0.10 ms faster for it, lesson 54 -- an epilogue of 9 000 - 17 000 instructions does not fit the
+// instruction cache two CUs share next to the other lane's kernels.
+template <typename T, int BM, int BN, int WMW, bool RED = false, bool DENSE = false>
 __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred,
                                             int64_t slab_off = 0) {      // f32 elements added to y (split-K: this split's slab)
     constexpr int WNW = 4 / WMW, RW = BM / WMW, WN = BN / WNW, TM = RW / 16, TN = WN / 16;
@@ -448,8 +453,8 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
     }
     const T* addend = (const T*)a.addend;
     const T* ysaved = (const T*)a.ysaved;
-    const bool vec_ok = (a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N &&
-                        (!a.nred || a.N % TN == 0);
+    const bool vec_ok = DENSE || ((a.ldy % TN == 0) && (!addend || a.ld_addend % TN == 0) && (!a.dact || a.ld_saved % TN == 0) && col0 + TN <= a.N &&
+                                  (!a.nred || a.N % TN == 0));
     typedef T __attribute__((ext_vector_type(TN))) RunT;      // TN consecutive values of one row, as loaded
     // Fused batch-norm backward reduction (capmi_igemm_nt_bnred): this launch's output is the dy of up to
     // two BN layers.  Target 0's sums are taken while the rows are stored; target 1 (rare) in a later pass.
@@ -480,7 +485,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 }
                 rows[r] = row;
             }
-            if (vec_ok) {
+            if (DENSE || vec_ok) {
                 // all loads of the four rows first (the output may alias the addend, so the compiler cannot
                 // hoist a row's loads over the previous row's store by itself: one memory latency, not four)
                 constexpr int RB = RED ? 2 : 4;      // rows per load batch (register budget)
@@ -522,7 +527,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                     }
                 }
                 }
-            } else {
+            } else if constexpr (!DENSE) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (!valid[r]) continue;
@@ -1002,7 +1007,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] += xch[(g * TM * TN + i * TN + j) * 256 + tid];
     }
-    nt_epilogue<T, BM, BN, WMW, RED>(a, acc, m0, n0, reinterpret_cast<float*>(smem), (int64_t)split * a.M * a.ldy);
+    nt_epilogue<T, BM, BN, WMW, RED, true>(a, acc, m0, n0, reinterpret_cast<float*>(smem), (int64_t)split * a.M * a.ldy);
 }
 
 template <int BM, int BN, int NST, bool RED = false, int LIN = 0>
@@ -1241,7 +1246,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // retire the (zero-page) tail issues before LDS reuse
     __syncthreads();
-    nt_epilogue<T, BM, BN, WMW, false>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
+    nt_epilogue<T, BM, BN, WMW, false, true>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
 }
 
 // Several independent problems (the parity classes of a strided data gradient) in ONE launch: the
@@ -1974,6 +1979,11 @@ extern "C" int capmi_lstm_step_bwd(const void* dgates_t, const void* whT, int ld
     return 0;
 }
 
+// The LDS-DMA kernel families store whole runs only (nt_epilogue DENSE): N and every row pitch of the epilogue a multiple of 8.
+static bool nt_dense(const IGemmArgs& a) {
+    return a.N % 8 == 0 && a.ldy % 8 == 0 && (!a.addend || a.ld_addend % 8 == 0) && (!a.dact || a.ld_saved % 8 == 0);
+}
+
 struct NtCfg { int bm, bn, wmw; };
 static NtCfg nt_cfg(int M, int N, int K, int dtype) {
     const bool wide = N > 64;
@@ -2109,7 +2119,7 @@ static bool nt_halo3_ok(const IGemmArgs& a, const capmi_conv_geom* g, int nred) 
 // (transform of the halo tile in LDS), 2 = the LDS-DMA kernel on a 1x1 convolution (transform of the A fragments), 0 = none.
 // Same tile selection as the plain call, so the statistics parts (capmi_igemm_nt_stats_part_rows) keep their height.
 static int nt_inbn_kind(const IGemmArgs& a, const capmi_conv_geom* g, const NtCfg& c, int nred, int dtype) {
-    if (dtype != CAPMI_BF16 || nred || g->Cin > INBN_KMAX || g->Cin % 32 != 0 || g->ldx != g->Cin) return 0;
+    if (dtype != CAPMI_BF16 || nred || g->Cin > INBN_KMAX || g->Cin % 32 != 0 || g->ldx != g->Cin || !nt_dense(a)) return 0;
     if (nt_halo3_ok(a, g, nred)) return 1;
     const bool lin = g->kh == 1 && g->kw == 1 && g->up == 1 && g->pad == 0 && (g->Ho - 1) * g->sd < g->Hi && (g->Wo - 1) * g->sd < g->Wi;
     const bool glds = c.wmw == 5 || c.bn == 128;
@@ -2127,6 +2137,13 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
         return 0;
     }
     const NtCfg c = nt_cfg(a.M, N, a.K, dtype);
+    if (dtype == CAPMI_BF16 && !nt_dense(a)) {
+        // ragged N or an odd pitch: the register-staged kernel (element-wise stores), same row-block height as the tile it replaces
+        // (capmi_igemm_nt_stats_part_rows stays valid)
+        CAPMI_CHECK(!a.in_a, "capmi_igemm_nt_bnact: N, ldy must be multiples of 8");
+        if (c.bm == 128) return launch_nt<bf16, 128, 64, 4>(a, st);
+        return launch_nt<bf16, 64, 64, 4>(a, st);
+    }
     if (a.in_a) {               // operand-path batch norm (capmi_igemm_nt_bnact): the two kernel families that carry it
         const int kind = nt_inbn_kind(a, g, c, nred, dtype);
         CAPMI_CHECK(kind != 0, "capmi_igemm_nt_bnact: this convolution has no operand-path batch-norm kernel (capmi_igemm_nt_bnact_supported)");
@@ -2286,7 +2303,7 @@ __global__ __launch_bounds__(256) void nt_splitk_reduce_kernel(const float* __re
 }
 static int nt_splitk_plan(int M, int N, int K, int* kper) {      // number of splits (1: not worth it) and the k range of one
     const int tiles = cdiv(M, 128) * cdiv(N, 128);
-    if (K < 4096 || tiles > 128 || N % 4 != 0) return 1;
+    if (K < 4096 || tiles > 128 || N % 8 != 0) return 1;
     int S = 256 / tiles;
     if (S > cdiv(K, 1024)) S = cdiv(K, 1024);                    // >= 32 k-steps per split
     if (S < 2) return 1;
@@ -2399,8 +2416,8 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
             const IGemmArgs& a = grp.a[i];
             const bool skinny = nt_uses_skinny(&c.g, a.M, a.K, false, dtype);
             const NtCfg cfg = nt_cfg(a.M, a.N, a.K, dtype);
-            fuse128 = fuse128 && !skinny && cfg.bn == 128 && cfg.wmw == 4;
-            fuse64 = fuse64 && !skinny && cfg.wmw == 5 && !nt_halo3_ok(a, &c.g, 0);
+            fuse128 = fuse128 && !skinny && cfg.bn == 128 && cfg.wmw == 4 && nt_dense(a);
+            fuse64 = fuse64 && !skinny && cfg.wmw == 5 && !nt_halo3_ok(a, &c.g, 0) && nt_dense(a);
             conv1 = conv1 && c.g.up == 1 && c.g.Cin >= 32;
             lin = lin && c.g.kh == 1 && c.g.kw == 1 && c.g.up == 1 && c.g.pad == 0 && (c.g.Ho - 1) * c.g.sd < c.g.Hi && (c.g.Wo - 1) * c.g.sd < c.g.Wi;
             blocks128 += ((long long)cdiv(a.M, 64) * cdiv(a.N, 128) + 7) / 8 * 8;      // ranges start at multiples of 8 (XCD order)
