@@ -419,7 +419,10 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
 // shapes ever execute -- is compiled out.  The LDS-DMA kernel families are DENSE-only (ragged launches take the register-staged
 // kernel): the same step runs 0.10 ms faster for it, lesson 54 -- an epilogue of 9 000 - 17 000 instructions does not fit the
 // instruction cache two CUs share next to the other lane's kernels.
-template <typename T, int BM, int BN, int WMW, bool RED = false, bool DENSE = false>
+// EPI = 1 (nt_conv_class, chosen on the host): the epilogue of a training convolution or of its data gradient -- no bias, no
+// inference batch norm, no output activation, storage-type output; an activation-derivative mask of relu / relu6 at most.  The
+// other paths (five activation forms per stored run, f32 slabs) are compiled out of those instantiations: code size again.
+template <typename T, int BM, int BN, int WMW, bool RED = false, bool DENSE = false, int EPI = 0>
 __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred,
                                             int64_t slab_off = 0) {      // f32 elements added to y (split-K: this split's slab)
     constexpr int WNW = 4 / WMW, RW = BM / WMW, WN = BN / WNW, TM = RW / 16, TN = WN / 16;
@@ -431,7 +434,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
     const int wcnt = min(RW, a.M - wrow0);                     // valid rows in it (<= 0: none)
     const int col0 = n0 + wn * WN + TN * fr;                   // this lane's TN consecutive columns
     const bool rows_full = wcnt == RW;
-    if (a.bn_a) {                   // the formula of bn_apply (mean subtracted before scaling), on the f32 accumulator
+    if (EPI == 0 && a.bn_a) {       // the formula of bn_apply (mean subtracted before scaling), on the f32 accumulator
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const bool ok = col0 + j < a.N;
@@ -441,7 +444,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = ca * (acc[i][j][r] - mu) + off;
         }
-    } else if (a.bias) {
+    } else if (EPI == 0 && a.bias) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float bias = col0 + j < a.N ? a.bias[col0 + j] : 0.f;
@@ -508,13 +511,18 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 #pragma unroll
                         for (int j = 0; j < TN; ++j) v[j] += (float)pa[r][j];
                     }
-                    act_run<TN>(v, a.act);
+                    if constexpr (EPI == 0) act_run<TN>(v, a.act);
                     if (a.dact) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) t[j] = (float)py[r][j];
-                        dact_run<TN>(v, t, a.dact);
+                        if constexpr (EPI == 0) dact_run<TN>(v, t, a.dact);
+                        else {
+                            const float hi = a.dact == CAPMI_ACT_RELU6 ? 6.f : __builtin_inff();      // relu / relu6 (nt_conv_class)
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) v[j] = (t[j] > 0.f && t[j] < hi) ? v[j] : 0.f;
+                        }
                     }
-                    if (a.out_f32) store_run<float, TN>((float*)a.y + slab_off + rows[r] * a.ldy + col0, v);
+                    if (EPI == 0 && a.out_f32) store_run<float, TN>((float*)a.y + slab_off + rows[r] * a.ldy + col0, v);
                     else store_run<T, TN>((T*)a.y + rows[r] * a.ldy + col0, v);
                     if constexpr (RED) {
 #pragma unroll
@@ -824,7 +832,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // (MobileNetV2.py:88-121: conv -> batch_norm -> relu is ONE unit of the reference graph; the unit boundary moves from
 // the producer's output to the consumer's operand).  With 4x1 waves every A row belongs to one wave, so the transform runs
 // once per staged element; per-channel coefficients come from a table in LDS.
-template <int BM, int BN, int NST, bool RED, int LIN, int KG = 1, int INBN_KC = 0>        // INBN_KC: channels the coefficient table holds (0: off)
+template <int BM, int BN, int NST, bool RED, int LIN, int KG = 1, int INBN_KC = 0, int EPI = 0>        // INBN_KC: channels the coefficient table holds (0: off)
 __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int nblocks) {
     typedef bf16 T;
     constexpr bool INBN = INBN_KC > 0;
@@ -1007,12 +1015,12 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] += xch[(g * TM * TN + i * TN + j) * 256 + tid];
     }
-    nt_epilogue<T, BM, BN, WMW, RED, true>(a, acc, m0, n0, reinterpret_cast<float*>(smem), (int64_t)split * a.M * a.ldy);
+    nt_epilogue<T, BM, BN, WMW, RED, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem), (int64_t)split * a.M * a.ldy);
 }
 
-template <int BM, int BN, int NST, bool RED = false, int LIN = 0>
+template <int BM, int BN, int NST, bool RED = false, int LIN = 0, int EPI = 0>
 __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_kernel(IGemmArgs a) {
-    nt_glds_body<BM, BN, NST, RED, LIN>(a, blockIdx.x, gridDim.x);
+    nt_glds_body<BM, BN, NST, RED, LIN, 1, 0, EPI>(a, blockIdx.x, gridDim.x);
 }
 
 // 1x1 convolution whose input is the producer's RAW output: batch norm + ReLU in the A-operand path (nt_glds_body, INBN)
@@ -1023,9 +1031,9 @@ __global__ __launch_bounds__(256, BM == 64 ? (KC <= 256 ? 4 : 3) : 2) void igemm
     nt_glds_body<BM, BN, 3, false, 1, 1, KC>(a, blockIdx.x, gridDim.x);
 }
 
-template <int BM, int BN, int NST, int LIN, int KG>
+template <int BM, int BN, int NST, int LIN, int KG, int EPI = 0>
 __global__ __launch_bounds__(256 * KG, (KG == 2 && BM == 64) ? 2 : 1) void igemm_nt_glds_kg_kernel(IGemmArgs a) {
-    nt_glds_body<BM, BN, NST, false, LIN, KG>(a, blockIdx.x, gridDim.x);
+    nt_glds_body<BM, BN, NST, false, LIN, KG, 0, EPI>(a, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------ 3x3 / stride 1 / pad 1: input tile staged ONCE per channel chunk
@@ -1046,7 +1054,7 @@ __global__ __launch_bounds__(256 * KG, (KG == 2 && BM == 64) ? 2 : 1) void igemm
 // they have landed from its own vmcnt; nobody else touches them) -- chunk 0's in the prologue, chunk c + 1's spread over
 // taps 2.. of chunk c, under that chunk's MFMAs, into the buffer nobody reads yet.  Padding / out-of-image rows are zeroed per
 // lane AFTER the fragment read (vmask), so what the transform makes of their zero-page bytes never reaches an MFMA.
-template <int BM, int BN, bool INBN = false>
+template <int BM, int BN, bool INBN = false, int EPI = 0>
 __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(IGemmArgs a) {
     typedef bf16 T;
     constexpr int BK = 32, WMW = 4;
@@ -1246,7 +1254,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // retire the (zero-page) tail issues before LDS reuse
     __syncthreads();
-    nt_epilogue<T, BM, BN, WMW, false, true>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
+    nt_epilogue<T, BM, BN, WMW, false, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
 }
 
 // Several independent problems (the parity classes of a strided data gradient) in ONE launch: the
@@ -1258,12 +1266,12 @@ struct NtGroup {
     int first[NT_GROUP_MAX + 1];
     int count;
 };
-template <int BM, int BN, int NST, int LIN>
+template <int BM, int BN, int NST, int LIN, int EPI = 0>
 __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 : 2)) void igemm_nt_glds_group_kernel(NtGroup g) {
     const int b = blockIdx.x;
     int p = 0;
     while (p + 1 < g.count && b >= g.first[p + 1]) ++p;
-    nt_glds_body<BM, BN, NST, false, LIN>(g.a[p], b - g.first[p], g.first[p + 1] - g.first[p]);
+    nt_glds_body<BM, BN, NST, false, LIN, 1, 0, EPI>(g.a[p], b - g.first[p], g.first[p + 1] - g.first[p]);
 }
 
 // ------------------------------------------------------------------ skinny NT kernel (M <= 64)
@@ -2059,15 +2067,15 @@ static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const
     return 0;
 }
 
-template <int BM, int BN>
-static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
+template <int BM, int BN, int EPI>
+static int launch_glds_epi(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
     const int64_t tiles = (int64_t)cdiv(a.M, BM) * cdiv(a.N, BN);
     CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
     const dim3 grid((unsigned)tiles);
     if constexpr (BM == 128) {
         if (!a.nred && tiles <= 256 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64))) {
-            if (lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2>), grid, dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2>), grid, dim3(512), 0, st, a);
+            if (lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2, EPI>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2, EPI>), grid, dim3(512), 0, st, a);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds 128, k-groups)");
             return 0;
         }
@@ -2077,20 +2085,30 @@ static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, b
         const bool k2 = !a.nred && tiles < 512 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64));
         const bool k4 = k2 && tiles <= 256 && a.K >= 2048 && (lin || g->Cin >= 128);
         if (k2) {
-            if (k4 && lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 4>), grid, dim3(1024), 0, st, a);
-            else if (k4) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 4>), grid, dim3(1024), 0, st, a);
-            else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2>), grid, dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2>), grid, dim3(512), 0, st, a);
+            if (k4 && lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 4, EPI>), grid, dim3(1024), 0, st, a);
+            else if (k4) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 4, EPI>), grid, dim3(1024), 0, st, a);
+            else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2, EPI>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2, EPI>), grid, dim3(512), 0, st, a);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds, k-groups)");
             return 0;
         }
     }
-    if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, true, 0>), grid, dim3(256), 0, st, a);
-    else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 1>), grid, dim3(256), 0, st, a);
-    else if (conv1) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 0>), grid, dim3(256), 0, st, a);
+    if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, true, 0, EPI>), grid, dim3(256), 0, st, a);
+    else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 1, EPI>), grid, dim3(256), 0, st, a);
+    else if (conv1) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 2, EPI>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 0, EPI>), grid, dim3(256), 0, st, a);
     CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
     return 0;
+}
+
+// The epilogue class of a launch (nt_epilogue EPI): 1 = a training convolution / its data gradient.
+static bool nt_conv_class(const IGemmArgs& a) {
+    return !a.bias && !a.bn_a && a.act == CAPMI_ACT_NONE && !a.out_f32 && a.ksplit <= 1 &&
+           (a.dact == CAPMI_ACT_NONE || a.dact == CAPMI_ACT_RELU || a.dact == CAPMI_ACT_RELU6);
+}
+template <int BM, int BN>
+static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
+    return nt_conv_class(a) ? launch_glds_epi<BM, BN, 1>(a, g, lin, conv1, st) : launch_glds_epi<BM, BN, 0>(a, g, lin, conv1, st);
 }
 
 // 3x3 / stride 1 / pad 1 "same" convolutions (forward, and the data gradient of one) on rows of <= 56 pixels, channels
@@ -2178,10 +2196,17 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
         const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(N, bn);
         CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
         const dim3 grid((unsigned)tiles);
-        if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128>), grid, dim3(256), 0, st, a);
-        else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64>), grid, dim3(256), 0, st, a);
-        else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64>), grid, dim3(256), 0, st, a);
+        if (nt_conv_class(a)) {
+            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 1>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 1>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 1>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 1>), grid, dim3(256), 0, st, a);
+        } else {
+            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64>), grid, dim3(256), 0, st, a);
+        }
         CAPMI_LAUNCH_CHECK("capmi_igemm_nt(halo 3x3)");
         return 0;
     }
@@ -2432,9 +2457,17 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
                 b += ((long long)cdiv(grp.a[i].M, 64) * cdiv(grp.a[i].N, fuse128 ? 128 : 64) + 7) / 8 * 8;
             }
             grp.first[n] = (int)b;
-            if (fuse128) {
+            bool cc = true;
+            for (int i = 0; i < n; ++i) cc = cc && nt_conv_class(grp.a[i]);
+            if (fuse128 && cc) {
+                if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            } else if (fuse128) {
                 if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
                 else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            } else if (cc) {
+                if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else {
                 if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
                 else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
