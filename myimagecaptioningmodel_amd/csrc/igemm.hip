@@ -422,6 +422,8 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
 // EPI = 1 (nt_conv_class, chosen on the host): the epilogue of a training convolution or of its data gradient -- no bias, no
 // inference batch norm, no output activation, storage-type output; an activation-derivative mask of relu / relu6 at most.  The
 // other paths (five activation forms per stored run, f32 slabs) are compiled out of those instantiations: code size again.
+// EPI = 2 (nt_fc_class): the decoder's fully connected layers and their data gradients -- bias and addend as in the general form,
+// activation / activation derivative tanh or none, storage-type output.
 template <typename T, int BM, int BN, int WMW, bool RED = false, bool DENSE = false, int EPI = 0>
 __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred,
                                             int64_t slab_off = 0) {      // f32 elements added to y (split-K: this split's slab)
@@ -434,7 +436,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
     const int wcnt = min(RW, a.M - wrow0);                     // valid rows in it (<= 0: none)
     const int col0 = n0 + wn * WN + TN * fr;                   // this lane's TN consecutive columns
     const bool rows_full = wcnt == RW;
-    if (EPI == 0 && a.bn_a) {       // the formula of bn_apply (mean subtracted before scaling), on the f32 accumulator
+    if (EPI == 0 && a.bn_a) {       // (EPI 1: neither; EPI 2: bias only) the formula of bn_apply (mean subtracted before scaling), on the f32 accumulator
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const bool ok = col0 + j < a.N;
@@ -444,7 +446,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = ca * (acc[i][j][r] - mu) + off;
         }
-    } else if (EPI == 0 && a.bias) {
+    } else if (EPI != 1 && a.bias) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float bias = col0 + j < a.N ? a.bias[col0 + j] : 0.f;
@@ -512,11 +514,20 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                         for (int j = 0; j < TN; ++j) v[j] += (float)pa[r][j];
                     }
                     if constexpr (EPI == 0) act_run<TN>(v, a.act);
+                    if constexpr (EPI == 2) {
+                        if (a.act) {
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) v[j] = tanhf_(v[j]);
+                        }
+                    }
                     if (a.dact) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) t[j] = (float)py[r][j];
                         if constexpr (EPI == 0) dact_run<TN>(v, t, a.dact);
-                        else {
+                        else if constexpr (EPI == 2) {
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) v[j] *= 1.f - t[j] * t[j];
+                        } else {
                             const float hi = a.dact == CAPMI_ACT_RELU6 ? 6.f : __builtin_inff();      // relu / relu6 (nt_conv_class)
 #pragma unroll
                             for (int j = 0; j < TN; ++j) v[j] = (t[j] > 0.f && t[j] < hi) ? v[j] : 0.f;
@@ -2106,9 +2117,16 @@ static bool nt_conv_class(const IGemmArgs& a) {
     return !a.bias && !a.bn_a && a.act == CAPMI_ACT_NONE && !a.out_f32 && a.ksplit <= 1 &&
            (a.dact == CAPMI_ACT_NONE || a.dact == CAPMI_ACT_RELU || a.dact == CAPMI_ACT_RELU6);
 }
+// 2 = a fully connected layer of the decoder / its data gradient (bias, addend; tanh or nothing on either side)
+static bool nt_fc_class(const IGemmArgs& a) {
+    return !a.bn_a && !a.out_f32 && a.ksplit <= 1 && !a.stats && !a.nred && (a.act == CAPMI_ACT_NONE || a.act == CAPMI_ACT_TANH) &&
+           (a.dact == CAPMI_ACT_NONE || a.dact == CAPMI_ACT_TANH);
+}
 template <int BM, int BN>
 static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
-    return nt_conv_class(a) ? launch_glds_epi<BM, BN, 1>(a, g, lin, conv1, st) : launch_glds_epi<BM, BN, 0>(a, g, lin, conv1, st);
+    if (nt_conv_class(a)) return launch_glds_epi<BM, BN, 1>(a, g, lin, conv1, st);
+    if (nt_fc_class(a)) return launch_glds_epi<BM, BN, 2>(a, g, lin, conv1, st);
+    return launch_glds_epi<BM, BN, 0>(a, g, lin, conv1, st);
 }
 
 // 3x3 / stride 1 / pad 1 "same" convolutions (forward, and the data gradient of one) on rows of <= 56 pixels, channels
