@@ -424,6 +424,8 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
 // other paths (five activation forms per stored run, f32 slabs) are compiled out of those instantiations: code size again.
 // EPI = 2 (nt_fc_class): the decoder's fully connected layers and their data gradients -- bias and addend as in the general form,
 // activation / activation derivative tanh or none, storage-type output.
+// EPI = 3 (nt_inf_class): a convolution of the inference graph (capmi_igemm_nt_bn) -- batch norm on the accumulator, residual
+// addend, relu / relu6 or nothing, storage-type output; no statistics, no derivative mask.
 template <typename T, int BM, int BN, int WMW, bool RED = false, bool DENSE = false, int EPI = 0>
 __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred,
                                             int64_t slab_off = 0) {      // f32 elements added to y (split-K: this split's slab)
@@ -436,7 +438,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
     const int wcnt = min(RW, a.M - wrow0);                     // valid rows in it (<= 0: none)
     const int col0 = n0 + wn * WN + TN * fr;                   // this lane's TN consecutive columns
     const bool rows_full = wcnt == RW;
-    if (EPI == 0 && a.bn_a) {       // (EPI 1: neither; EPI 2: bias only) the formula of bn_apply (mean subtracted before scaling), on the f32 accumulator
+    if ((EPI == 0 || EPI == 3) && a.bn_a) {       // (EPI 1: neither; EPI 2: bias only) the formula of bn_apply (mean subtracted before scaling), on the f32 accumulator
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const bool ok = col0 + j < a.N;
@@ -446,7 +448,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = ca * (acc[i][j][r] - mu) + off;
         }
-    } else if (EPI != 1 && a.bias) {
+    } else if ((EPI == 0 || EPI == 2) && a.bias) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float bias = col0 + j < a.N ? a.bias[col0 + j] : 0.f;
@@ -520,7 +522,14 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                             for (int j = 0; j < TN; ++j) v[j] = tanhf_(v[j]);
                         }
                     }
-                    if (a.dact) {
+                    if constexpr (EPI == 3) {
+                        if (a.act) {
+                            const float hi = a.act == CAPMI_ACT_RELU6 ? 6.f : __builtin_inff();
+#pragma unroll
+                            for (int j = 0; j < TN; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.f, hi);
+                        }
+                    }
+                    if (EPI != 3 && a.dact) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) t[j] = (float)py[r][j];
                         if constexpr (EPI == 0) dact_run<TN>(v, t, a.dact);
@@ -584,7 +593,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
             }
         }
     }
-    if (a.stats) {
+    if (EPI <= 1 && a.stats) {
         // (after the output stores have been issued: the statistics -- two LDS round trips -- then run while the stores
         // drain; in front of them they cost +42 % on the write-bound 64 -> 256 1x1 layer, tools/nt_ablate.hip)
         // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) per column of this workgroup's
@@ -593,7 +602,9 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
         // formula; ONE part per workgroup row block is stored (plain stores, one producer per
         // (part, column): deterministic).  bn_finalize (bn_ops.hip) merges the parts in f64.
         // sred: [WMW][BN][2] floats of LDS scratch (the staging tiles are free now)
-        __syncthreads();
+        // (LDS-only barriers: __syncthreads() is also `s_waitcnt vmcnt(0)`, i.e. it made every workgroup wait for its output
+        // tile's stores to be acknowledged before it could start on the statistics)
+        lds_barrier();
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s1 = 0.f;
@@ -618,7 +629,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 sred[(wm * BN + c) * 2 + 1] = m2;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < BN && n0 + tid < a.N && m0 < a.M) {
             float ntot = 0.f, msum = 0.f;
 #pragma unroll
@@ -1016,7 +1027,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         }
         __syncthreads();
         if (grp > 0) {                  // keep the barrier count of the epilogue's statistics path (two), then leave
-            if (a.stats) { __syncthreads(); __syncthreads(); }
+            if (a.stats) { lds_barrier(); lds_barrier(); }
             return;
         }
 #pragma unroll
@@ -2122,10 +2133,16 @@ static bool nt_fc_class(const IGemmArgs& a) {
     return !a.bn_a && !a.out_f32 && a.ksplit <= 1 && !a.stats && !a.nred && (a.act == CAPMI_ACT_NONE || a.act == CAPMI_ACT_TANH) &&
            (a.dact == CAPMI_ACT_NONE || a.dact == CAPMI_ACT_TANH);
 }
+// 3 = a convolution of the inference graph (capmi_igemm_nt_bn)
+static bool nt_inf_class(const IGemmArgs& a) {
+    return a.bn_a && !a.out_f32 && a.ksplit <= 1 && !a.stats && !a.nred && !a.dact &&
+           (a.act == CAPMI_ACT_NONE || a.act == CAPMI_ACT_RELU || a.act == CAPMI_ACT_RELU6);
+}
 template <int BM, int BN>
 static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
     if (nt_conv_class(a)) return launch_glds_epi<BM, BN, 1>(a, g, lin, conv1, st);
     if (nt_fc_class(a)) return launch_glds_epi<BM, BN, 2>(a, g, lin, conv1, st);
+    if (nt_inf_class(a)) return launch_glds_epi<BM, BN, 3>(a, g, lin, conv1, st);
     return launch_glds_epi<BM, BN, 0>(a, g, lin, conv1, st);
 }
 
@@ -2219,6 +2236,11 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
             else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 1>), grid, dim3(256), 0, st, a);
             else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 1>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 1>), grid, dim3(256), 0, st, a);
+        } else if (nt_inf_class(a)) {
+            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 3>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 3>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 3>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 3>), grid, dim3(256), 0, st, a);
         } else {
             if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128>), grid, dim3(256), 0, st, a);
             else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64>), grid, dim3(256), 0, st, a);
