@@ -419,9 +419,10 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
 // shapes ever execute -- is compiled out.  The LDS-DMA kernel families are DENSE-only (ragged launches take the register-staged
 // kernel): the same step runs 0.10 ms faster for it, lesson 54 -- an epilogue of 9 000 - 17 000 instructions does not fit the
 // instruction cache two CUs share next to the other lane's kernels.
-// EPI = 1 (nt_conv_class, chosen on the host): the epilogue of a training convolution or of its data gradient -- no bias, no
-// inference batch norm, no output activation, storage-type output; an activation-derivative mask of relu / relu6 at most.  The
-// other paths (five activation forms per stored run, f32 slabs) are compiled out of those instantiations: code size again.
+// EPI = 1 / 4 (nt_conv_class, chosen on the host): the epilogue of a training convolution (1: plain stores + the fused
+// statistics) or of its data gradient (4: addend, relu / relu6 derivative mask, output scatter; no statistics) -- no bias, no
+// inference batch norm, no output activation, storage-type output.  The other paths (five activation forms per stored run, f32
+// slabs) are compiled out of those instantiations: code size again.
 // EPI = 2 (nt_fc_class): the decoder's fully connected layers and their data gradients -- bias and addend as in the general form,
 // activation / activation derivative tanh or none, storage-type output.
 // EPI = 3 (nt_inf_class): a convolution of the inference graph (capmi_igemm_nt_bn) -- batch norm on the accumulator, residual
@@ -485,7 +486,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 const int rl = i * 16 + fg * 4 + r;
                 valid[r] = rows_full || rl < wcnt;
                 int64_t row = wrow0 + rl;
-                if (a.g.os > 1 && valid[r]) {  // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
+                if (EPI != 1 && a.g.os > 1 && valid[r]) {  // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
                     const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
                     const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
                     row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
@@ -501,8 +502,8 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 RunT pa[4], py[4], px[4];
 #pragma unroll
                 for (int r = h; r < h + RB; ++r) {
-                    if (addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
-                    if (a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
+                    if (EPI != 1 && addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
+                    if (EPI != 1 && EPI != 3 && a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
                     if (RED && valid[r]) px[r] = *reinterpret_cast<const RunT*>(rx0 + rows[r] * a.N + col0);
                 }
 #pragma unroll
@@ -511,7 +512,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                     float v[TN], t[TN];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
-                    if (addend) {
+                    if (EPI != 1 && addend) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) v[j] += (float)pa[r][j];
                     }
@@ -529,7 +530,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                             for (int j = 0; j < TN; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.f, hi);
                         }
                     }
-                    if (EPI != 3 && a.dact) {
+                    if (EPI != 1 && EPI != 3 && a.dact) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) t[j] = (float)py[r][j];
                         if constexpr (EPI == 0) dact_run<TN>(v, t, a.dact);
@@ -593,7 +594,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
             }
         }
     }
-    if (EPI <= 1 && a.stats) {
+    if (EPI <= 1 && a.stats) {      // (EPI 2 / 3 / 4 never carry statistics)
         // (after the output stores have been issued: the statistics -- two LDS round trips -- then run while the stores
         // drain; in front of them they cost +42 % on the write-bound 64 -> 256 1x1 layer, tools/nt_ablate.hip)
         // Fused batch-norm statistics: exact (mean, M2 = sum (v-mean)^2) per column of this workgroup's
@@ -2115,8 +2116,14 @@ static int launch_glds_epi(const IGemmArgs& a, const capmi_conv_geom* g, bool li
             return 0;
         }
     }
-    if (a.nred) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, true, 0, EPI>), grid, dim3(256), 0, st, a);
-    else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 1, EPI>), grid, dim3(256), 0, st, a);
+    if constexpr (EPI == 0 || EPI == 4) {       // (the fused batch-norm backward sums ride on data gradients only)
+        if (a.nred) {
+            hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, true, 0, EPI>), grid, dim3(256), 0, st, a);
+            CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
+            return 0;
+        }
+    }
+    if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 1, EPI>), grid, dim3(256), 0, st, a);
     else if (conv1) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 2, EPI>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 0, EPI>), grid, dim3(256), 0, st, a);
     CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
@@ -2128,6 +2135,8 @@ static bool nt_conv_class(const IGemmArgs& a) {
     return !a.bias && !a.bn_a && a.act == CAPMI_ACT_NONE && !a.out_f32 && a.ksplit <= 1 &&
            (a.dact == CAPMI_ACT_NONE || a.dact == CAPMI_ACT_RELU || a.dact == CAPMI_ACT_RELU6);
 }
+// conv class: 1 = the forward form (nothing but stores and statistics), 4 = the data-gradient form (no statistics)
+static bool nt_conv_fwd(const IGemmArgs& a) { return !a.addend && !a.dact && a.g.os <= 1 && !a.nred; }
 // 2 = a fully connected layer of the decoder / its data gradient (bias, addend; tanh or nothing on either side)
 static bool nt_fc_class(const IGemmArgs& a) {
     return !a.bn_a && !a.out_f32 && a.ksplit <= 1 && !a.stats && !a.nred && (a.act == CAPMI_ACT_NONE || a.act == CAPMI_ACT_TANH) &&
@@ -2140,7 +2149,7 @@ static bool nt_inf_class(const IGemmArgs& a) {
 }
 template <int BM, int BN>
 static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
-    if (nt_conv_class(a)) return launch_glds_epi<BM, BN, 1>(a, g, lin, conv1, st);
+    if (nt_conv_class(a)) return nt_conv_fwd(a) ? launch_glds_epi<BM, BN, 1>(a, g, lin, conv1, st) : launch_glds_epi<BM, BN, 4>(a, g, lin, conv1, st);
     if (nt_fc_class(a)) return launch_glds_epi<BM, BN, 2>(a, g, lin, conv1, st);
     if (nt_inf_class(a)) return launch_glds_epi<BM, BN, 3>(a, g, lin, conv1, st);
     return launch_glds_epi<BM, BN, 0>(a, g, lin, conv1, st);
@@ -2231,11 +2240,16 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
         const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(N, bn);
         CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
         const dim3 grid((unsigned)tiles);
-        if (nt_conv_class(a)) {
+        if (nt_conv_class(a) && nt_conv_fwd(a)) {
             if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 1>), grid, dim3(256), 0, st, a);
             else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 1>), grid, dim3(256), 0, st, a);
             else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 1>), grid, dim3(256), 0, st, a);
             else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 1>), grid, dim3(256), 0, st, a);
+        } else if (nt_conv_class(a) && !a.stats) {
+            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 4>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 4>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 4>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 4>), grid, dim3(256), 0, st, a);
         } else if (nt_inf_class(a)) {
             if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 3>), grid, dim3(256), 0, st, a);
             else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 3>), grid, dim3(256), 0, st, a);
@@ -2498,16 +2512,16 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
             }
             grp.first[n] = (int)b;
             bool cc = true;
-            for (int i = 0; i < n; ++i) cc = cc && nt_conv_class(grp.a[i]);
+            for (int i = 0; i < n; ++i) cc = cc && nt_conv_class(grp.a[i]) && !grp.a[i].stats;      // (groups carry no statistics: the data-gradient form)
             if (fuse128 && cc) {
-                if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
-                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (fuse128) {
                 if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
                 else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (cc) {
-                if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
-                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else {
                 if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
                 else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
