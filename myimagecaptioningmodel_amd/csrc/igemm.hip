@@ -606,6 +606,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
         // (LDS-only barriers: __syncthreads() is also `s_waitcnt vmcnt(0)`, i.e. it made every workgroup wait for its output
         // tile's stores to be acknowledged before it could start on the statistics)
         lds_barrier();
+        const float inv_cnt = wcnt > 0 ? 1.f / (float)wcnt : 0.f;       // one division per lane, not one per column (exact for full 16 / 32-row blocks)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float s1 = 0.f;
@@ -614,7 +615,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (rows_full || i * 16 + fg * 4 + r < wcnt) s1 += acc[i][j][r];
-            const float mean = wcnt > 0 ? row4_sum(s1) / (float)wcnt : 0.f;
+            const float mean = row4_sum(s1) * inv_cnt;
             float m2 = 0.f;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
