@@ -31,6 +31,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$out/dec" -- 
 python3 tools/trace_by_shape.py "$out/dec" 13 > "$out/${tag}_decode_beam5_by_shape.txt"
 rm -rf "$out/dec"
 # operand-path batch norm (capmi_igemm_nt_bnact), levels 0 / 1 / 2: step time (3 alternating runs each) and the per-queue kernel tables
+# (SKIP_INBN=1 leaves that evidence file as recorded)
+if [ "${SKIP_INBN:-0}" != "1" ]; then
 {
   echo "# CAPMI_INBN A/B on one box: ms per step, images/s (bench.py --steps 40 --warmup 8, three alternating runs)"
   for i in 1 2 3; do for e in CAPMI_INBN=0 CAPMI_INBN=1 CAPMI_INBN=2; do
@@ -41,5 +43,6 @@ rm -rf "$out/dec"
 bash tools/prof_ab.sh "$out/inbn" CAPMI_INBN=0 CAPMI_INBN=1 CAPMI_INBN=2
 for i in 1 2 3; do { echo; echo "# $(cat $out/inbn/env_$i.txt): kernel time per queue (rocprofv3 --kernel-trace of bench.py --steps 10 --warmup 3)"; head -26 "$out/inbn/by_queue_$i.txt"; echo "# ... per shape (the convolutions that carry the operand path, and bn_apply):"; grep -E "halo3|inbn|bn_apply|igemm_nt_glds_kernel<(64, 128|128, 128)" "$out/inbn/by_shape_$i.txt" | head -24; } >> "$out/${tag}_inbn_ab.txt"; done
 rm -rf "$out/inbn"
+fi
 rm -rf "$out/stats" "$out/trace" "$out/pmc_fetch" "$out/pmc_write"
 ls -la "$out"
