@@ -427,6 +427,8 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
 // activation / activation derivative tanh or none, storage-type output.
 // EPI = 3 (nt_inf_class): a convolution of the inference graph (capmi_igemm_nt_bn) -- batch norm on the accumulator, residual
 // addend, relu / relu6 or nothing, storage-type output; no statistics, no derivative mask.
+// EPI = 5 (nt_f32_class): a plain product with an f32 output and at most a bias -- the vocabulary projection's logits
+// (model_adaAttention_aic.py:25), once per train step and once per decode step.
 template <typename T, int BM, int BN, int WMW, bool RED = false, bool DENSE = false, int EPI = 0>
 __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred,
                                             int64_t slab_off = 0) {      // f32 elements added to y (split-K: this split's slab)
@@ -449,7 +451,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = ca * (acc[i][j][r] - mu) + off;
         }
-    } else if ((EPI == 0 || EPI == 2) && a.bias) {
+    } else if ((EPI == 0 || EPI == 2 || EPI == 5) && a.bias) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const float bias = col0 + j < a.N ? a.bias[col0 + j] : 0.f;
@@ -502,8 +504,8 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 RunT pa[4], py[4], px[4];
 #pragma unroll
                 for (int r = h; r < h + RB; ++r) {
-                    if (EPI != 1 && addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
-                    if (EPI != 1 && EPI != 3 && a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
+                    if (EPI != 1 && EPI != 5 && addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
+                    if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
                     if (RED && valid[r]) px[r] = *reinterpret_cast<const RunT*>(rx0 + rows[r] * a.N + col0);
                 }
 #pragma unroll
@@ -512,7 +514,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                     float v[TN], t[TN];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
-                    if (EPI != 1 && addend) {
+                    if (EPI != 1 && EPI != 5 && addend) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) v[j] += (float)pa[r][j];
                     }
@@ -530,7 +532,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                             for (int j = 0; j < TN; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.f, hi);
                         }
                     }
-                    if (EPI != 1 && EPI != 3 && a.dact) {
+                    if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) t[j] = (float)py[r][j];
                         if constexpr (EPI == 0) dact_run<TN>(v, t, a.dact);
@@ -543,7 +545,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                             for (int j = 0; j < TN; ++j) v[j] = (t[j] > 0.f && t[j] < hi) ? v[j] : 0.f;
                         }
                     }
-                    if (EPI == 0 && a.out_f32) store_run<float, TN>((float*)a.y + slab_off + rows[r] * a.ldy + col0, v);
+                    if (EPI == 5 || (EPI == 0 && a.out_f32)) store_run<float, TN>((float*)a.y + slab_off + rows[r] * a.ldy + col0, v);
                     else store_run<T, TN>((T*)a.y + rows[r] * a.ldy + col0, v);
                     if constexpr (RED) {
 #pragma unroll
@@ -2148,11 +2150,16 @@ static bool nt_inf_class(const IGemmArgs& a) {
     return a.bn_a && !a.out_f32 && a.ksplit <= 1 && !a.stats && !a.nred && !a.dact &&
            (a.act == CAPMI_ACT_NONE || a.act == CAPMI_ACT_RELU || a.act == CAPMI_ACT_RELU6);
 }
+// 5 = a plain product with an f32 output (+ bias): the logits of the vocabulary projection
+static bool nt_f32_class(const IGemmArgs& a) {
+    return a.out_f32 && !a.bn_a && a.ksplit <= 1 && !a.stats && !a.nred && !a.addend && a.act == CAPMI_ACT_NONE && a.dact == CAPMI_ACT_NONE;
+}
 template <int BM, int BN>
 static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
     if (nt_conv_class(a)) return nt_conv_fwd(a) ? launch_glds_epi<BM, BN, 1>(a, g, lin, conv1, st) : launch_glds_epi<BM, BN, 4>(a, g, lin, conv1, st);
     if (nt_fc_class(a)) return launch_glds_epi<BM, BN, 2>(a, g, lin, conv1, st);
     if (nt_inf_class(a)) return launch_glds_epi<BM, BN, 3>(a, g, lin, conv1, st);
+    if (nt_f32_class(a)) return launch_glds_epi<BM, BN, 5>(a, g, lin, conv1, st);
     return launch_glds_epi<BM, BN, 0>(a, g, lin, conv1, st);
 }
 
@@ -2514,12 +2521,16 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
             grp.first[n] = (int)b;
             bool cc = true;
             for (int i = 0; i < n; ++i) cc = cc && nt_conv_class(grp.a[i]) && !grp.a[i].stats;      // (groups carry no statistics: the data-gradient form)
+            bool fc = !cc;
+            for (int i = 0; i < n; ++i) fc = fc && nt_fc_class(grp.a[i]);
             if (fuse128 && cc) {
                 if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
                 else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (fuse128) {
                 if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
                 else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            } else if (fc && lin) {         // the decode step's grouped projections (bias, tanh)
+                hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (cc) {
                 if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
                 else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
