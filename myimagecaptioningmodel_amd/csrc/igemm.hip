@@ -2023,7 +2023,11 @@ static NtCfg nt_cfg(int M, int N, int K, int dtype) {
     const bool wide = N > 64;
     if (dtype == CAPMI_BF16) {
         if (wide) {
-            const bool big = K >= 512 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 384;   // LDS-DMA pipeline kernel: deep K, full grid
+            // 128-row tiles from K = 128 on (512 until the epilogues shrank, lesson 54: with ~1 000 instructions of prologue + epilogue per
+            // wave the K <= 256 layers are bound by instruction issue, and a 128-row tile pays the prologue and the statistics once
+            // per 128 rows: 8.31 -> 8.26 ms per step; K = 64 gains nothing).  CAPMI_NT_BIGK overrides.
+            static const int big_k = getenv("CAPMI_NT_BIGK") ? atoi(getenv("CAPMI_NT_BIGK")) : 128;
+            const bool big = K >= big_k && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 384;   // LDS-DMA pipeline kernel: full grid
             const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128);
             if (!big && K >= 1024 && t128 >= 160 && t128 <= 256) return NtCfg{128, 128, 4};      // one round of 128x128 tiles, two k-groups each
             if (!big && (int64_t)cdiv(M, 64) * cdiv(N, 128) < 256) return NtCfg{64, 64, 5};      // under-filled grid: 64x64 LDS-DMA tiles (wmw 5 = marker)
