@@ -2027,12 +2027,18 @@ static NtCfg nt_cfg(int M, int N, int K, int dtype) {
             // wave the K <= 256 layers are bound by instruction issue, and a 128-row tile pays the prologue and the statistics once
             // per 128 rows: 8.31 -> 8.26 ms per step; K = 64 gains nothing).  CAPMI_NT_BIGK overrides.
             static const int big_k = getenv("CAPMI_NT_BIGK") ? atoi(getenv("CAPMI_NT_BIGK")) : 128;
-            const bool big = K >= big_k && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 384;   // LDS-DMA pipeline kernel: full grid
+            static const int big_tiles = getenv("CAPMI_NT_BIGTILES") ? atoi(getenv("CAPMI_NT_BIGTILES")) : 384;      // experiment knob
+            const bool big = K >= big_k && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= big_tiles;   // LDS-DMA pipeline kernel: full grid
             const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128);
             if (!big && K >= 1024 && t128 >= 160 && t128 <= 256) return NtCfg{128, 128, 4};      // one round of 128x128 tiles, two k-groups each
             if (!big && (int64_t)cdiv(M, 64) * cdiv(N, 128) < 256) return NtCfg{64, 64, 5};      // under-filled grid: 64x64 LDS-DMA tiles (wmw 5 = marker)
             return NtCfg{big ? 128 : 64, 128, 4};
         }
+        // tall grids of narrow outputs (the 64-channel 56 x 56 layers): 128 x 64 tiles pay the prologue, the statistics and (3 x 3)
+        // the halo once per 128 rows (wmw 6 = marker).  CAPMI_NT_TALL64 = minimum number of 128-row blocks, 0 = never.
+        // (8.235 -> 8.195 ms per step at cfg 2 with 1 024; lesson 54.)
+        static const int tall64 = getenv("CAPMI_NT_TALL64") ? atoi(getenv("CAPMI_NT_TALL64")) : 1024;
+        if (N >= 32 && tall64 > 0 && cdiv(M, 128) >= tall64) return NtCfg{128, 64, 6};
         if (N >= 32) return NtCfg{64, 64, 5};          // LDS-DMA 64x64 tiles
         const bool tall = cdiv(M, 128) >= 512;
         return NtCfg{tall ? 128 : 64, 64, 4};
@@ -2280,6 +2286,7 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
         const bool lin = g->kh == 1 && g->kw == 1 && g->up == 1 && g->pad == 0 && (g->Ho - 1) * g->sd < g->Hi && (g->Wo - 1) * g->sd < g->Wi;
         const bool conv1 = !lin && g->up == 1 && g->Cin >= 32;
         if (c.wmw == 5) return launch_glds<64, 64>(a, g, lin, conv1, st);           // 64x64 LDS-DMA tiles
+        if (c.wmw == 6) return launch_glds<128, 64>(a, g, lin, conv1, st);          // 128x64 LDS-DMA tiles
         if (c.bn == 128 && c.bm == 128) return launch_glds<128, 128>(a, g, lin, conv1, st);
         if (c.bn == 128) return launch_glds<64, 128>(a, g, lin, conv1, st);
         if (c.bm == 128 && c.bn == 64) return launch_nt<bf16, 128, 64, 4>(a, st);

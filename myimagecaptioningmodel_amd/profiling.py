@@ -31,14 +31,15 @@ def _nt_tile(M, N, K, bf16):
     wide = N > 64
     if bf16:
         if wide:
-            big = K >= int(os.environ.get('CAPMI_NT_BIGK', '128')) and cd(M, 128) * cd(N, 128) >= 384
+            big = K >= int(os.environ.get('CAPMI_NT_BIGK', '128')) and cd(M, 128) * cd(N, 128) >= int(os.environ.get('CAPMI_NT_BIGTILES', '384'))
             if not big and K >= 1024 and 160 <= cd(M, 128) * cd(N, 128) <= 256:
                 return (128, 128, True)
             if not big and cd(M, 64) * cd(N, 128) < 256:
                 return (64, 64, True)
             return (128 if big else 64, 128, True)
         if N >= 32:
-            return (64, 64, True)
+            tall64 = int(os.environ.get('CAPMI_NT_TALL64', '1024'))
+            return (128, 64, True) if (tall64 > 0 and cd(M, 128) >= tall64) else (64, 64, True)
         return (128 if cd(M, 128) >= 512 else 64, 64, False)
     tall = cd(M, 128) * cd(N, 64) >= 256
     return (64, 128, False) if wide else ((128 if tall else 64), 64, False)
