@@ -2023,10 +2023,11 @@ static NtCfg nt_cfg(int M, int N, int K, int dtype) {
     const bool wide = N > 64;
     if (dtype == CAPMI_BF16) {
         if (wide) {
-            // 128-row tiles from K = 128 on (512 until the epilogues shrank, lesson 54: with ~1 000 instructions of prologue + epilogue per
+            // 128-row tiles from K = 64 on (512 until the epilogues shrank, lesson 54: with ~1 000 instructions of prologue + epilogue per
             // wave the K <= 256 layers are bound by instruction issue, and a 128-row tile pays the prologue and the statistics once
-            // per 128 rows: 8.31 -> 8.26 ms per step; K = 64 gains nothing).  CAPMI_NT_BIGK overrides.
-            static const int big_k = getenv("CAPMI_NT_BIGK") ? atoi(getenv("CAPMI_NT_BIGK")) : 128;
+            // per 128 rows: train step 8.31 -> 8.26 ms with 128; 64 leaves the train step where it is and takes the beam-5 decode at
+            // batch 128 from 21 300 to 22 100 captions/s).  CAPMI_NT_BIGK overrides.
+            static const int big_k = getenv("CAPMI_NT_BIGK") ? atoi(getenv("CAPMI_NT_BIGK")) : 64;
             static const int big_tiles = getenv("CAPMI_NT_BIGTILES") ? atoi(getenv("CAPMI_NT_BIGTILES")) : 384;      // experiment knob
             const bool big = K >= big_k && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= big_tiles;   // LDS-DMA pipeline kernel: full grid
             const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128);
