@@ -1054,7 +1054,7 @@ __global__ __launch_bounds__(256, BM == 64 ? (NST == 3 ? 4 : 3) : (NST == 3 ? 3 
 // plain kernel's 4 workgroups per CU up to 256 input channels; one workgroup per CU fewer cost a whole round on the 14x14 layers)
 template <int BM, int BN, int KC>
 __global__ __launch_bounds__(256, BM == 64 ? (KC <= 256 ? 4 : 3) : 2) void igemm_nt_glds_inbn_kernel(IGemmArgs a) {
-    nt_glds_body<BM, BN, 3, false, 1, 1, KC>(a, blockIdx.x, gridDim.x);
+    nt_glds_body<BM, BN, 3, false, 1, 1, KC, 1>(a, blockIdx.x, gridDim.x);      // (always a training convolution's forward form)
 }
 
 template <int BM, int BN, int NST, int LIN, int KG, int EPI = 0>
@@ -2234,10 +2234,10 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
         CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt_bnact: grid too large");
         const dim3 grid((unsigned)tiles);
         if (kind == 1) {
-            if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, true>), grid, dim3(256), 0, st, a);
-            else if (bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, true>), grid, dim3(256), 0, st, a);
-            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, true>), grid, dim3(256), 0, st, a);
+            if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, true, 1>), grid, dim3(256), 0, st, a);
+            else if (bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, true, 1>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, true, 1>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, true, 1>), grid, dim3(256), 0, st, a);
         } else {
 #define CAPMI_INBN_LAUNCH(BM_, BN_)                                                                                              \
             do {                                                                                                                 \
