@@ -74,6 +74,11 @@ def pmc_traffic(label):
                or k.startswith('_Z20igemm_nt_glds_kernelILi%sELi%sE' % (g.group(1), g.group(2)))]
     else:
         hit = [v for k, v in kernels.items() if re.search(r'\b%s\b' % re.escape(label), k)]
+    if g and len(hit) > 1:
+        # one label = every instantiation of that tile (addressing mode, epilogue class): launch-weighted mean over them
+        n = sum(v['launches'] for v in hit)
+        hit = [dict(hbm_bytes_per_launch=sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit) / max(n, 1))]
+        source['rows'] = 'launch-weighted mean over the instantiations of this tile'
     if len(hit) != 1:
         return None, source
     # stale profile: the kernels changed since the pass was recorded (checkable only where the git history is present --
