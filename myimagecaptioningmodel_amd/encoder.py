@@ -141,7 +141,7 @@ class EncoderRunner:
         self.draws = [z((max_elems,)) for _ in range(int(os.environ.get('CAPMI_RING', '6')))] if need_backward else None
         self.draw = self.draws[0] if need_backward else None
         self.overlap_wgrad = True
-        self.overlap_forward = True     # projection shortcuts of the forward pass on the side lane
+        self.overlap_forward = os.environ.get('CAPMI_FWD_SIDE', '1') != '0'     # projection shortcuts of the forward pass on the side lane
         self.draw_side = z((max_elems,)) if need_backward else None     # raw-output gradient of a projection shortcut (side lane)
         ws = 0
         for op in enc.ops:
