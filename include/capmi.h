@@ -41,6 +41,13 @@ const char* capmi_last_error(void);
 int capmi_deterministic(void);
 int capmi_set_deterministic(int on);
 
+/* Verification switch (default off, or CAPMI_NT_GENERAL=1): every capmi_igemm_nt* launch runs the general epilogue instantiation
+ * instead of the epilogue class the library would pick for it (training convolution forward / data gradient, decoder fc,
+ * inference convolution, f32 logits -- the same arithmetic with the paths that launch cannot take compiled out, which is what keeps
+ * the kernels within the instruction cache).  Results are bit-identical either way; tests hold them to it. */
+int capmi_general_epilogue(void);
+int capmi_set_general_epilogue(int on);
+
 /* Alternates.  Four entry points are NOT on the default launch plans: each is a fused form that measured slower than
  * the launches it replaces on the ResNet-50 workload, is kept because it is the faster form at other sizes or the
  * per-step fallback of a fused kernel, and is covered by the same parity tests as the default path:

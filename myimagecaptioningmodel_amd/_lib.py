@@ -124,6 +124,8 @@ QUERIES = {
     'capmi_bn_bwd_ws_floats': [_i, _i, _i],
     'capmi_deterministic': [],
     'capmi_set_deterministic': [_i],
+    'capmi_general_epilogue': [],
+    'capmi_set_general_epilogue': [_i],
 }
 
 # lane synchronisation (no stream-last convention): name -> argument ctypes
@@ -216,6 +218,15 @@ def set_deterministic(on):
     L = lib()
     prev = bool(L.capmi_deterministic())
     L.capmi_set_deterministic(1 if on else 0)
+    return prev
+
+
+def set_general_epilogue(on):
+    """capmi_set_general_epilogue (include/capmi.h): every NT launch on the general epilogue instantiation instead of its
+    epilogue class (verification: the classes must be bit-identical to it).  Returns the previous setting."""
+    L = lib()
+    prev = bool(L.capmi_general_epilogue())
+    L.capmi_set_general_epilogue(1 if on else 0)
     return prev
 
 

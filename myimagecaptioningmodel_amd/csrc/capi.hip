@@ -31,6 +31,24 @@ extern "C" int capmi_set_deterministic(int on) {
     return 0;
 }
 
+// ------------------------------------------------------------------ general epilogue (verification)
+// CAPMI_NT_GENERAL=1 (or capmi_set_general_epilogue(1)): every NT launch runs the GENERAL epilogue instantiation (class 0) instead
+// of its class (convolution forward / data gradient, decoder fc, inference, f32 logits: igemm.hip nt_epilogue EPI).  The classes
+// are the same arithmetic with the paths a launch cannot take compiled out; this switch lets a test hold them to the general form
+// bit for bit.
+static int g_general_epilogue = -1;
+extern "C" int capmi_general_epilogue(void) {
+    if (g_general_epilogue < 0) {
+        const char* e = getenv("CAPMI_NT_GENERAL");
+        g_general_epilogue = (e && e[0] && e[0] != '0') ? 1 : 0;
+    }
+    return g_general_epilogue;
+}
+extern "C" int capmi_set_general_epilogue(int on) {
+    g_general_epilogue = on ? 1 : 0;
+    return 0;
+}
+
 // ------------------------------------------------------------------ lane synchronisation
 // Device-scope events for ordering two HIP streams of the SAME device (plan lanes).  Created without
 // timing and without the system-scope release a default hipEventRecord performs (an L2 write-back that

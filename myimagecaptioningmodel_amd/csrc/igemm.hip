@@ -2146,24 +2146,24 @@ static int launch_glds_epi(const IGemmArgs& a, const capmi_conv_geom* g, bool li
 
 // The epilogue class of a launch (nt_epilogue EPI): 1 = a training convolution / its data gradient.
 static bool nt_conv_class(const IGemmArgs& a) {
-    return !a.bias && !a.bn_a && a.act == CAPMI_ACT_NONE && !a.out_f32 && a.ksplit <= 1 &&
+    return !capmi_general_epilogue() && !a.bias && !a.bn_a && a.act == CAPMI_ACT_NONE && !a.out_f32 && a.ksplit <= 1 &&
            (a.dact == CAPMI_ACT_NONE || a.dact == CAPMI_ACT_RELU || a.dact == CAPMI_ACT_RELU6);
 }
 // conv class: 1 = the forward form (nothing but stores and statistics), 4 = the data-gradient form (no statistics)
 static bool nt_conv_fwd(const IGemmArgs& a) { return !a.addend && !a.dact && a.g.os <= 1 && !a.nred; }
 // 2 = a fully connected layer of the decoder / its data gradient (bias, addend; tanh or nothing on either side)
 static bool nt_fc_class(const IGemmArgs& a) {
-    return !a.bn_a && !a.out_f32 && a.ksplit <= 1 && !a.stats && !a.nred && (a.act == CAPMI_ACT_NONE || a.act == CAPMI_ACT_TANH) &&
+    return !capmi_general_epilogue() && !a.bn_a && !a.out_f32 && a.ksplit <= 1 && !a.stats && !a.nred && (a.act == CAPMI_ACT_NONE || a.act == CAPMI_ACT_TANH) &&
            (a.dact == CAPMI_ACT_NONE || a.dact == CAPMI_ACT_TANH);
 }
 // 3 = a convolution of the inference graph (capmi_igemm_nt_bn)
 static bool nt_inf_class(const IGemmArgs& a) {
-    return a.bn_a && !a.out_f32 && a.ksplit <= 1 && !a.stats && !a.nred && !a.dact &&
+    return !capmi_general_epilogue() && a.bn_a && !a.out_f32 && a.ksplit <= 1 && !a.stats && !a.nred && !a.dact &&
            (a.act == CAPMI_ACT_NONE || a.act == CAPMI_ACT_RELU || a.act == CAPMI_ACT_RELU6);
 }
 // 5 = a plain product with an f32 output (+ bias): the logits of the vocabulary projection
 static bool nt_f32_class(const IGemmArgs& a) {
-    return a.out_f32 && !a.bn_a && a.ksplit <= 1 && !a.stats && !a.nred && !a.addend && a.act == CAPMI_ACT_NONE && a.dact == CAPMI_ACT_NONE;
+    return !capmi_general_epilogue() && a.out_f32 && !a.bn_a && a.ksplit <= 1 && !a.stats && !a.nred && !a.addend && a.act == CAPMI_ACT_NONE && a.dact == CAPMI_ACT_NONE;
 }
 template <int BM, int BN>
 static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {

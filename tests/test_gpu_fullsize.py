@@ -112,6 +112,25 @@ def test_two_lane_schedule_equals_the_single_stream_order(full, monkeypatch, det
     assert torch.equal(g1, g0), float((g1 - g0).abs().max())
 
 
+def test_epilogue_classes_equal_the_general_epilogue_at_full_size(full, deterministic):
+    """Every NT launch of the step on the GENERAL epilogue instantiation (capmi_set_general_epilogue) instead of its epilogue
+    class (DESIGN.md lesson 54): the same loss and the same gradients BIT FOR BIT at full size -- the classes only compile
+    paths out.  (The inference class is held to the general form in tests/test_gpu_kernels.py: a decode replays a captured
+    graph, whose kernels are fixed at capture.)"""
+    from myimagecaptioningmodel_amd import _lib
+    cfg, eng, image, cap, params = full
+    l0 = _loss(eng, image, cap)
+    g0 = eng.store.grad[:eng.store.trainable_size].clone()
+    prev = _lib.set_general_epilogue(True)
+    try:
+        l1 = _loss(eng, image, cap)
+        g1 = eng.store.grad[:eng.store.trainable_size].clone()
+    finally:
+        _lib.set_general_epilogue(prev)
+    assert l1 == l0, (l0, l1)
+    assert torch.equal(g1, g0), float((g1 - g0).abs().max())
+
+
 def test_inference_decode_is_idempotent_and_beam_one_is_greedy(full):
     """is_test batch norm reads the running statistics and changes no state (MobileNetV2.py:111-119 with is_test):
     decoding the same images twice gives the same ids bit for bit, and a beam of one is the greedy loop (:119-123)."""

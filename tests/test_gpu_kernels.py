@@ -667,6 +667,79 @@ def test_conv_with_inference_batch_norm_in_the_epilogue(dtype, B, C, H, W, Co, k
     assert float(d) <= tol * max(1.0, float(Y2.float().abs().max())), float(d)
 
 
+@pytest.mark.parametrize('B,C,H,W,Co,k,s', [(4, 64, 56, 56, 256, 1, 1),       # 128 x 128 tiles, K = 64
+                                             (4, 256, 56, 56, 64, 1, 1),       # 128 x 64 tiles (tall grid, narrow output)
+                                             (8, 128, 28, 28, 128, 3, 1),      # halo kernel
+                                             (64, 1024, 14, 14, 256, 1, 1),    # k-group kernel
+                                             (8, 256, 28, 28, 512, 1, 2),      # strided 1 x 1 (projection shortcut)
+                                             (16, 512, 7, 7, 512, 3, 1)])      # 7 x 7: 64 x 64 k-group tiles
+def test_epilogue_classes_equal_the_general_epilogue(B, C, H, W, Co, k, s):
+    """The NT kernels carry their epilogue as a class chosen per launch (training convolution forward: stores + statistics;
+    data gradient: addend + ReLU mask; decoder fc: bias / tanh; inference: batch norm + ReLU; f32 logits) -- the same arithmetic
+    with the paths the launch cannot take compiled out (DESIGN.md lesson 54).  Every class must reproduce the general epilogue
+    (capmi_set_general_epilogue) BIT FOR BIT."""
+    _lib, tdt, code = _env()
+    dtype = 'bf16'
+    rng = np.random.RandomState(B + C + Co + k + s)
+    f32 = torch.float32
+    pad = 1 if k == 3 else 0
+    Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
+    M, K = B * Ho * Wo, k * k * C
+    X = dev(rng.standard_normal((B, H, W, C)) + 0.3, tdt[dtype])
+    Wk = dev(rng.standard_normal((Co, k, k, C)) / np.sqrt(K), tdt[dtype])
+    g = _lib.ConvGeom(B, H, W, C, Ho, Wo, k, k, s, 1, pad, C)
+    pr = _lib.lib().capmi_igemm_nt_stats_part_rows(M, Co, K, code[dtype])
+    nparts = (M + pr - 1) // pr
+    bias = dev(rng.standard_normal(Co) * 0.2, f32)
+    mean, ca = dev(rng.standard_normal(Co) * 0.1, f32), dev(rng.uniform(0.5, 1.5, Co), f32)
+    RES = dev(rng.standard_normal((B, Ho, Wo, Co)), tdt[dtype])
+    YS = dev(rng.standard_normal((B, Ho, Wo, Co)), tdt[dtype])          # a saved activation output (mask / tanh source)
+    relu, tanh = _lib.ACT_CODES['relu'], _lib.ACT_CODES['tanh']
+
+    def run():
+        outs = []
+        # 1: training convolution, forward form (statistics)
+        Y = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+        st = torch.zeros((nparts + 64, Co, 2), dtype=f32, device=DEV)
+        _lib.call('capmi_igemm_nt', p(X), p(Wk), p(Y), g, Co, K, Co, None, None, 0, None, 0, p(st), 0, 0, 0, code[dtype], stream())
+        outs += [Y, st[:nparts]]
+        # 4: data-gradient form (addend + ReLU mask), on the same geometry
+        Y = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+        _lib.call('capmi_igemm_nt', p(X), p(Wk), p(Y), g, Co, K, Co, None, p(RES), Co, p(YS), Co, None, 0, relu, 0, code[dtype], stream())
+        outs.append(Y)
+        # 2: fc form (bias + tanh; tanh derivative with an addend)
+        Y = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+        _lib.call('capmi_igemm_nt', p(X), p(Wk), p(Y), g, Co, K, Co, p(bias), None, 0, None, 0, None, tanh, 0, 0, code[dtype], stream())
+        outs.append(Y)
+        Y = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+        _lib.call('capmi_igemm_nt', p(X), p(Wk), p(Y), g, Co, K, Co, None, p(RES), Co, p(YS), Co, None, 0, tanh, 0, code[dtype], stream())
+        outs.append(Y)
+        # 3: inference form (batch norm on the accumulator + residual + ReLU)
+        Y = torch.zeros((B, Ho, Wo, Co), dtype=tdt[dtype], device=DEV)
+        _lib.call('capmi_igemm_nt_bn', p(X), p(Wk), p(Y), g, Co, K, Co, p(mean), p(ca), p(bias), p(RES), Co, relu, code[dtype], stream())
+        outs.append(Y)
+        # 5: f32 output with a bias (logits)
+        Y = torch.zeros((B, Ho, Wo, Co), dtype=f32, device=DEV)
+        _lib.call('capmi_igemm_nt', p(X), p(Wk), p(Y), g, Co, K, Co, p(bias), None, 0, None, 0, None, 0, 0, 1, code[dtype], stream())
+        outs.append(Y)
+        torch.cuda.synchronize()
+        _KEEP.extend(outs)
+        return outs
+
+    prev = _lib.set_general_epilogue(False)
+    try:
+        cls = run()
+        _lib.set_general_epilogue(True)
+        gen = run()
+    finally:
+        _lib.set_general_epilogue(prev)
+    names = ['conv forward', 'its statistics', 'data gradient (addend, relu mask)', 'fc (bias, tanh)', 'fc gradient (addend, tanh derivative)',
+             'inference conv + batch norm', 'f32 logits']
+    for n_, a_, b_ in zip(names, cls, gen):
+        assert torch.equal(a_, b_), (n_, int((a_ != b_).sum()))
+    assert float(cls[0].float().abs().max()) > 0 and float(cls[2].float().abs().max()) > 0
+
+
 @pytest.mark.parametrize('dtype', ['bf16', 'f32'])
 @pytest.mark.parametrize('B,C,H,W,Co,k,s', [(64, 1024, 14, 14, 256, 1, 1),     # k-group kernel, 128 x 128 tiles, 98 parts: two levels
                                              (64, 256, 14, 14, 256, 3, 1),      # halo kernel, 196 workgroups, two levels
