@@ -26,6 +26,11 @@ extern "C" {
 #define CAPMI_ABI_VERSION 1
 enum { CAPMI_F32 = 0, CAPMI_BF16 = 1 };
 enum { CAPMI_ACT_NONE = 0, CAPMI_ACT_RELU = 1, CAPMI_ACT_RELU6 = 2, CAPMI_ACT_TANH = 3, CAPMI_ACT_SIGMOID = 4 };
+/* `dact` of capmi_igemm_nt / capmi_igemm_nt_group may carry this flag (dact = CAPMI_ACT_RELU | CAPMI_DACT_BITMASK): ysaved then is
+ * the activation-derivative BIT MASK capmi_bn_apply_mask wrote ([rows][ld_saved / 8] bytes, ld_saved = channels per row) instead
+ * of the saved output itself -- 1/16 of the bytes in the epilogue that masks a ReLU tensor's gradient.  bf16 convolution data
+ * gradients only (relu / relu6; N, ldy, ld_saved, ld_addend multiples of 8; no bias / activation / f32 output). */
+#define CAPMI_DACT_BITMASK 0x100
 
 int capmi_version(void);
 const char* capmi_last_error(void);
@@ -254,6 +259,12 @@ int capmi_bn_finalize(float* ws, int part_rows, int M, int C, const float* scale
                       int update_running, void* stream);
 int capmi_bn_apply(const void* x, const float* saved_mean, const float* coef_a, const float* offset,
                    const void* res, void* y, int M, int C, int act, int dtype, void* stream);
+/* capmi_bn_apply + the activation-derivative bit mask of the STORED output: mask[m][c >> 3] bit (c & 7) = 1 where
+ * act'(y[m][c]) = 1 (relu: y > 0; relu6: 0 < y < 6) -- batch_norm -> relu of MobileNetV2.py:112-121 with what its backward
+ * needs of the output kept at one bit per element.  bf16, C % 8 == 0, act relu / relu6; mask: M * C / 8 bytes.
+ * Consumer: dact | CAPMI_DACT_BITMASK (above). */
+int capmi_bn_apply_mask(const void* x, const float* saved_mean, const float* coef_a, const float* offset, const void* res,
+                        void* y, uint8_t* mask, int M, int C, int act, int dtype, void* stream);
 /* capmi_bn_bwd_reduce / capmi_bn_bwd_apply without the dependent second-stage launch between them (~50 per train step, ~9 us
  * each on the critical chain): the reduction ADDS its block totals (f32 atomics; a wave instruction covers 256 contiguous
  * bytes, at most 1/8 of the grid per address) into eight accumulator rows acc8[8][2C] -- zeroed by the caller once per

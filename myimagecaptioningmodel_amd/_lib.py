@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get('CAPMI_LIB') or os.path.join(_HERE, 'libcapmi.so')
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
+DACT_BITMASK = 0x100      # capmi.h CAPMI_DACT_BITMASK
 ACT_CODES = {None: ACT_NONE, 'relu': ACT_RELU, 'relu6': ACT_RELU6, 'tanh': ACT_TANH, 'sigmoid': ACT_SIGMOID}
 
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     'capmi_bn_stats': [_p, _i, _i, _p, _i, _p],
     'capmi_bn_finalize': [_p, _i, _i, _i, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p],
     'capmi_bn_apply': [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    'capmi_bn_apply_mask': [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_inference_coef': [_p, _p, _p, _f, _p, _p, _i, _p],
     'capmi_bn_inference_coef_batched': [_p, _i, _i, _f, _p],
     'capmi_bn_finalize_apply': [_p, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _i, _p, _p, _p, _i, _i, _p],

@@ -355,11 +355,15 @@ extern "C" int capmi_bn_inference_coef(const float* scale, const float* run_mean
 // ACT >= 0: compile-time activation (none / relu / relu6, what the encoders use); ACT < 0: the run-time code `act`.
 // U rows are loaded as one batch before any arithmetic (see bn_bwd_reduce_kernel: with the run-time switch in the loop
 // the compiler kept one or two loads in flight per thread).
-template <typename T, int ACT, bool RES>
+// MASK (capmi_bn_apply_mask, bf16): next to y the kernel stores one bit per element -- "the activation's derivative at this
+// output is 1", from the ROUNDED value it stores -- as a byte per 8 channels ([M][C / 8]); the data-gradient epilogue that
+// masks this tensor's gradient reads the bits (CAPMI_DACT_BITMASK, igemm.hip EPI 6) instead of y itself: 1/16 of the bytes.
+template <typename T, int ACT, bool RES, bool MASK = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ ca,
                                                        const float* __restrict__ offset, const T* __restrict__ res, T* __restrict__ y,
-                                                       int M, int C, int act, ColLayout L) {
+                                                       uint8_t* __restrict__ mask, int M, int C, int act, ColLayout L) {
     constexpr int VEC = Vec<T>::N;
+    static_assert(!MASK || (VEC == 8 && ACT > 0), "the bit mask is a byte per thread and row: bf16, relu / relu6");
     constexpr int U = 4;
     const int cc = threadIdx.x % L.cpc, rr = threadIdx.x / L.cpc;
     const int chunk = blockIdx.y * L.cpc + cc;
@@ -375,14 +379,17 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     const int m_begin = blockIdx.x * L.rows_per_block;
     const int m_end = min(M, m_begin + L.rows_per_block);
     const int64_t step = (int64_t)L.rp * C;
-    auto one = [&](const Vec<T>& xv, const Vec<T>& rv) {
+    auto one = [&](const Vec<T>& xv, const Vec<T>& rv, int64_t o) {
         Vec<T> ov;
+        unsigned bits = 0;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
             float f = a[v] * (xv.get(v) - mu[v]) + b[v];
             if (RES) f += rv.get(v);
             ov.set(v, apply_act(f, ACT >= 0 ? ACT : act));
+            if (MASK) bits |= (act_grad_from_out(ov.get(v), ACT) != 0.f ? 1u : 0u) << v;
         }
+        if (MASK) mask[o >> 3] = (uint8_t)bits;
         return ov;
     };
     int m = m_begin + rr;
@@ -396,12 +403,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the batch: the scheduler otherwise sinks every load to its use (one in flight)
 #pragma unroll
-        for (int u = 0; u < U; ++u) vstore<T>(y + off + u * step, one(xv[u], rv[u]));
+        for (int u = 0; u < U; ++u) vstore<T>(y + off + u * step, one(xv[u], rv[u], off + u * step));
     }
     for (; m < m_end; m += L.rp, off += step) {
         Vec<T> xv = vload<T>(x + off), rv;
         if (RES) rv = vload<T>(res + off);
-        vstore<T>(y + off, one(xv, rv));
+        vstore<T>(y + off, one(xv, rv, off));
     }
 }
 
@@ -409,10 +416,10 @@ template <typename T, bool RES>
 static void bn_apply_launch(int act, dim3 grid, hipStream_t st, const T* x, const float* mean, const float* ca, const float* offset, const T* res,
                             T* y, int M, int C, const ColLayout& L) {
     switch (act) {
-        case CAPMI_ACT_NONE: hipLaunchKernelGGL((bn_apply_kernel<T, CAPMI_ACT_NONE, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, M, C, act, L); break;
-        case CAPMI_ACT_RELU: hipLaunchKernelGGL((bn_apply_kernel<T, CAPMI_ACT_RELU, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, M, C, act, L); break;
-        case CAPMI_ACT_RELU6: hipLaunchKernelGGL((bn_apply_kernel<T, CAPMI_ACT_RELU6, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, M, C, act, L); break;
-        default: hipLaunchKernelGGL((bn_apply_kernel<T, -1, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, M, C, act, L); break;
+        case CAPMI_ACT_NONE: hipLaunchKernelGGL((bn_apply_kernel<T, CAPMI_ACT_NONE, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, nullptr, M, C, act, L); break;
+        case CAPMI_ACT_RELU: hipLaunchKernelGGL((bn_apply_kernel<T, CAPMI_ACT_RELU, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, nullptr, M, C, act, L); break;
+        case CAPMI_ACT_RELU6: hipLaunchKernelGGL((bn_apply_kernel<T, CAPMI_ACT_RELU6, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, nullptr, M, C, act, L); break;
+        default: hipLaunchKernelGGL((bn_apply_kernel<T, -1, RES>), grid, dim3(256), 0, st, x, mean, ca, offset, res, y, nullptr, M, C, act, L); break;
     }
 }
 
@@ -427,6 +434,26 @@ extern "C" int capmi_bn_apply(const void* x, const float* saved_mean, const floa
         else bn_apply_launch<T, false>(act, dim3(gx, gy), (hipStream_t)stream, (const T*)x, saved_mean, coef_a, offset, (const T*)res, (T*)y, M, C, L);
     });
     CAPMI_LAUNCH_CHECK("capmi_bn_apply");
+    return 0;
+}
+/* capmi_bn_apply that also writes the activation-derivative bit mask of its output (bf16, relu / relu6, C % 8 == 0): see capmi.h. */
+extern "C" int capmi_bn_apply_mask(const void* x, const float* saved_mean, const float* coef_a, const float* offset, const void* res,
+                                   void* y, uint8_t* mask, int M, int C, int act, int dtype, void* stream) {
+    CAPMI_CHECK(x && saved_mean && coef_a && offset && y && mask, "capmi_bn_apply_mask: null pointer");
+    CAPMI_CHECK(dtype == CAPMI_BF16 && C % 8 == 0 && (act == CAPMI_ACT_RELU || act == CAPMI_ACT_RELU6),
+                "capmi_bn_apply_mask: bf16 tensors with C %% 8 == 0 and a relu / relu6 activation only (C=%d act=%d dtype=%d)", C, act, dtype);
+    typedef bf16 T;
+    int gx, gy;
+    ColLayout L = ew_layout(M, C, 8, &gx, &gy);
+    const dim3 grid(gx, gy);
+    hipStream_t st = (hipStream_t)stream;
+#define CAPMI_BN_APPLY_MASK(ACT_, RES_)                                                                                                            \
+    hipLaunchKernelGGL((bn_apply_kernel<T, ACT_, RES_, true>), grid, dim3(256), 0, st, (const T*)x, saved_mean, coef_a, offset, (const T*)res, (T*)y, \
+                       mask, M, C, act, L)
+    if (act == CAPMI_ACT_RELU) { if (res) CAPMI_BN_APPLY_MASK(CAPMI_ACT_RELU, true); else CAPMI_BN_APPLY_MASK(CAPMI_ACT_RELU, false); }
+    else { if (res) CAPMI_BN_APPLY_MASK(CAPMI_ACT_RELU6, true); else CAPMI_BN_APPLY_MASK(CAPMI_ACT_RELU6, false); }
+#undef CAPMI_BN_APPLY_MASK
+    CAPMI_LAUNCH_CHECK("capmi_bn_apply_mask");
     return 0;
 }
 

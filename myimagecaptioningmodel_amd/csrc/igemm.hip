@@ -285,6 +285,13 @@ template <int TN> __device__ __forceinline__ void act_run(float (&v)[TN], int ac
         default: break;
     }
 }
+// a mask byte carried in one element of an operand vector (the bit-mask form shares the registers of the saved-output form)
+template <typename T> __device__ __forceinline__ T bits_to_elem(unsigned b);
+template <> __device__ __forceinline__ bf16 bits_to_elem<bf16>(unsigned b) { return __builtin_bit_cast(bf16, (unsigned short)b); }
+template <> __device__ __forceinline__ float bits_to_elem<float>(unsigned b) { return __builtin_bit_cast(float, b); }
+template <typename T> __device__ __forceinline__ unsigned elem_to_bits(T e);
+template <> __device__ __forceinline__ unsigned elem_to_bits<bf16>(bf16 e) { return (unsigned)__builtin_bit_cast(unsigned short, e); }
+template <> __device__ __forceinline__ unsigned elem_to_bits<float>(float e) { return __builtin_bit_cast(unsigned, e); }
 template <int TN> __device__ __forceinline__ void dact_run(float (&v)[TN], const float (&y)[TN], int dact) {
     switch (dact) {
         case CAPMI_ACT_RELU:
@@ -427,6 +434,8 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
 // activation / activation derivative tanh or none, storage-type output.
 // EPI = 3 (nt_inf_class): a convolution of the inference graph (capmi_igemm_nt_bn) -- batch norm on the accumulator, residual
 // addend, relu / relu6 or nothing, storage-type output; no statistics, no derivative mask.
+// EPI = 6: the data-gradient form (4) whose ReLU mask comes as BITS (dact | CAPMI_DACT_BITMASK: a byte per 8 channels that
+// capmi_bn_apply_mask wrote in the forward pass) instead of the saved activation itself -- 1/16 of the mask's bytes.
 // EPI = 5 (nt_f32_class): a plain product with an f32 output and at most a bias -- the vocabulary projection's logits
 // (model_adaAttention_aic.py:25), once per train step and once per decode step.
 template <typename T, int BM, int BN, int WMW, bool RED = false, bool DENSE = false, int EPI = 0>
@@ -505,7 +514,9 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 #pragma unroll
                 for (int r = h; r < h + RB; ++r) {
                     if (EPI != 1 && EPI != 5 && addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
-                    if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
+                    if constexpr (EPI == 6) {
+                        if (valid[r]) py[r][0] = bits_to_elem<T>(reinterpret_cast<const uint8_t*>(a.ysaved)[(rows[r] * a.ld_saved + col0) >> 3]);
+                    } else if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
                     if (RED && valid[r]) px[r] = *reinterpret_cast<const RunT*>(rx0 + rows[r] * a.N + col0);
                 }
 #pragma unroll
@@ -532,7 +543,11 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                             for (int j = 0; j < TN; ++j) v[j] = __builtin_amdgcn_fmed3f(v[j], 0.f, hi);
                         }
                     }
-                    if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact) {
+                    if constexpr (EPI == 6) {
+                        const unsigned m = elem_to_bits<T>(py[r][0]) >> (col0 & 7);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) v[j] = ((m >> j) & 1u) ? v[j] : 0.f;
+                    } else if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) t[j] = (float)py[r][j];
                         if constexpr (EPI == 0) dact_run<TN>(v, t, a.dact);
@@ -2090,6 +2105,12 @@ static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const
     a.M = g->B * g->Ho * g->Wo; a.N = N; a.K = g->kh * g->kw * g->Cin;
     a.ldw = ldw; a.ldy = ldy; a.ld_addend = ld_addend; a.ld_saved = ld_saved;
     a.g = *g; a.act = act; a.dact = dact; a.out_f32 = out_f32;
+    if (dact & CAPMI_DACT_BITMASK) {
+        const int base = dact & (CAPMI_DACT_BITMASK - 1);
+        CAPMI_CHECK(dtype == CAPMI_BF16 && (base == CAPMI_ACT_RELU || base == CAPMI_ACT_RELU6) && N % 8 == 0 && ld_saved % 8 == 0 && ldy % 8 == 0 &&
+                        (!addend || ld_addend % 8 == 0) && !nred && !bias && !act && !out_f32 && !stats && !(g->Hi == 1 && g->Wi == 1) && N >= 32,
+                    "capmi_igemm_nt: CAPMI_DACT_BITMASK is for bf16 convolution data gradients (relu / relu6; N, ldy, ld_saved, ld_addend multiples of 8; no bias / activation / statistics / f32 output)");
+    }
     a.nred = nred;
     for (int q = 0; q < 2; ++q) {
         a.rx[q] = q < nred ? red[q].x : nullptr; a.rmean[q] = q < nred ? red[q].mean : nullptr;
@@ -2149,6 +2170,8 @@ static bool nt_conv_class(const IGemmArgs& a) {
     return !capmi_general_epilogue() && !a.bias && !a.bn_a && a.act == CAPMI_ACT_NONE && !a.out_f32 && a.ksplit <= 1 &&
            (a.dact == CAPMI_ACT_NONE || a.dact == CAPMI_ACT_RELU || a.dact == CAPMI_ACT_RELU6);
 }
+// the data-gradient form with its mask as bits (the flag forces the class: no other epilogue reads bits)
+static bool nt_bits_class(const IGemmArgs& a) { return (a.dact & CAPMI_DACT_BITMASK) != 0; }
 // conv class: 1 = the forward form (nothing but stores and statistics), 4 = the data-gradient form (no statistics)
 static bool nt_conv_fwd(const IGemmArgs& a) { return !a.addend && !a.dact && a.g.os <= 1 && !a.nred; }
 // 2 = a fully connected layer of the decoder / its data gradient (bias, addend; tanh or nothing on either side)
@@ -2167,6 +2190,7 @@ static bool nt_f32_class(const IGemmArgs& a) {
 }
 template <int BM, int BN>
 static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
+    if (nt_bits_class(a)) return launch_glds_epi<BM, BN, 6>(a, g, lin, conv1, st);
     if (nt_conv_class(a)) return nt_conv_fwd(a) ? launch_glds_epi<BM, BN, 1>(a, g, lin, conv1, st) : launch_glds_epi<BM, BN, 4>(a, g, lin, conv1, st);
     if (nt_fc_class(a)) return launch_glds_epi<BM, BN, 2>(a, g, lin, conv1, st);
     if (nt_inf_class(a)) return launch_glds_epi<BM, BN, 3>(a, g, lin, conv1, st);
@@ -2259,7 +2283,12 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
         const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(N, bn);
         CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
         const dim3 grid((unsigned)tiles);
-        if (nt_conv_class(a) && nt_conv_fwd(a)) {
+        if (nt_bits_class(a)) {
+            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 6>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 6>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 6>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 6>), grid, dim3(256), 0, st, a);
+        } else if (nt_conv_class(a) && nt_conv_fwd(a)) {
             if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 1>), grid, dim3(256), 0, st, a);
             else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 1>), grid, dim3(256), 0, st, a);
             else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 1>), grid, dim3(256), 0, st, a);
@@ -2516,7 +2545,7 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
             const bool skinny = nt_uses_skinny(&c.g, a.M, a.K, false, dtype);
             const NtCfg cfg = nt_cfg(a.M, a.N, a.K, dtype);
             fuse128 = fuse128 && !skinny && cfg.bn == 128 && cfg.wmw == 4 && nt_dense(a);
-            fuse64 = fuse64 && !skinny && cfg.wmw == 5 && !nt_halo3_ok(a, &c.g, 0) && nt_dense(a);
+            fuse64 = fuse64 && !skinny && cfg.wmw == 5 && !nt_halo3_ok(a, &c.g, 0) && nt_dense(a) && !nt_bits_class(a);      // (no 64-wide group kernel reads mask bits)
             conv1 = conv1 && c.g.up == 1 && c.g.Cin >= 32;
             lin = lin && c.g.kh == 1 && c.g.kw == 1 && c.g.up == 1 && c.g.pad == 0 && (c.g.Ho - 1) * c.g.sd < c.g.Hi && (c.g.Wo - 1) * c.g.sd < c.g.Wi;
             blocks128 += ((long long)cdiv(a.M, 64) * cdiv(a.N, 128) + 7) / 8 * 8;      // ranges start at multiples of 8 (XCD order)
@@ -2524,7 +2553,9 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
         }
         grp.count = n;
         const long long blocks = fuse128 ? blocks128 : blocks64;
-        if ((fuse128 || fuse64) && blocks < (1ll << 31)) {
+        bool mixed = false;      // a group either reads mask bits in every call or in none
+        { bool any = false, all = true; for (int i = 0; i < n; ++i) { any = any || nt_bits_class(grp.a[i]); all = all && nt_bits_class(grp.a[i]); } mixed = any && !all; }
+        if ((fuse128 || fuse64) && !mixed && blocks < (1ll << 31)) {
             long long b = 0;
             for (int i = 0; i < n; ++i) {
                 grp.first[i] = (int)b;
@@ -2533,9 +2564,14 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
             grp.first[n] = (int)b;
             bool cc = true;
             for (int i = 0; i < n; ++i) cc = cc && nt_conv_class(grp.a[i]) && !grp.a[i].stats;      // (groups carry no statistics: the data-gradient form)
+            bool allbits = true, anybits = false;
+            for (int i = 0; i < n; ++i) { allbits = allbits && nt_bits_class(grp.a[i]); anybits = anybits || nt_bits_class(grp.a[i]); }
             bool fc = !cc;
             for (int i = 0; i < n; ++i) fc = fc && nt_fc_class(grp.a[i]);
-            if (fuse128 && cc) {
+            if (fuse128 && allbits) {
+                if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            } else if (fuse128 && cc) {
                 if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
                 else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (fuse128) {

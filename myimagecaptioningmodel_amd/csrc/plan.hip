@@ -72,6 +72,7 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_bn_stats),
     CAPMI_ENTRY(capmi_bn_finalize),
     CAPMI_ENTRY(capmi_bn_apply),
+    CAPMI_ENTRY(capmi_bn_apply_mask),
     CAPMI_ENTRY(capmi_bn_inference_coef),
     CAPMI_ENTRY(capmi_bn_inference_coef_batched),
     CAPMI_ENTRY(capmi_bn_finalize_apply),

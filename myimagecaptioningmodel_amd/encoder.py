@@ -18,7 +18,7 @@ import os
 import torch
 
 from . import arch
-from ._lib import ACT_CODES, WGRAD_WS_BYTES, ConvGeom, NtCall, PtrSlot, lib, wgrad_workspace
+from ._lib import ACT_CODES, DACT_BITMASK, WGRAD_WS_BYTES, ConvGeom, NtCall, PtrSlot, lib, wgrad_workspace
 from .params import stem_s2d
 
 BN_MOMENTUM = 0.9      # fluid.layers.batch_norm defaults; MobileNetV2.py:112-117 overrides neither
@@ -157,6 +157,19 @@ class EncoderRunner:
         # finalizes when the library is built with -DCAPMI_FIN=1).  Measured slower than the dependent launch it removes (DESIGN.md
         # lesson 48): off by default.
         self.bnfin = os.environ.get('CAPMI_BNFIN', '0') != '0'
+        # activation-derivative bit masks (capmi_bn_apply_mask): one bit per element of every ReLU / ReLU6 tensor, written next to the
+        # activated tensor in the forward pass; the data-gradient epilogue that masks the tensor's gradient reads them instead of the
+        # tensor (1/16 of the bytes on the backward chain; igemm.hip EPI 6).  bf16 only; CAPMI_MASKBITS (experiment, default off).
+        self.maskbits = {}
+        if (need_backward and dtype_code == 1 and os.environ.get('CAPMI_MASKBITS', '0') != '0' and not self.fuse_bn_reduce
+                and os.environ.get('CAPMI_INBN', '0') == '0'):
+            for op in enc.ops:
+                if isinstance(op, arch.ConvBN) and id(op) not in self.skipped:
+                    fa = self.fused_add.get(op.dst)
+                    out_id, act = (fa.dst, fa.act) if fa is not None else (op.dst, op.act)
+                    h, w, c = self.shape[out_id]
+                    if act in ('relu', 'relu6') and c % 8 == 0 and c >= 32 and out_id != enc.out:
+                        self.maskbits[out_id] = z((B * h * w * c // 8,), torch.uint8)
         self.bn_acc, off = {}, 0
         for op in enc.ops:
             if isinstance(op, arch.ConvBN) and id(op) not in self.skipped:
@@ -341,8 +354,11 @@ class EncoderRunner:
                 fa = self.fused_add.get(op.dst)
                 fused_here = (not is_test) and M <= self.fa_max_rows
 
-                def apply(res, out, act, lane):
-                    if fused_here:
+                def apply(res, out, act, lane, out_id=None):
+                    bits = self.maskbits.get(out_id) if (out_id is not None and not is_test) else None
+                    if bits is not None and not fused_here:
+                        plan.add('capmi_bn_apply_mask', _p(raw), _p(bn['mean']), _p(bn['a']), offset, res, out, _p(bits), M, c, act, code, lane=lane)
+                    elif fused_here:
                         plan.add('capmi_bn_finalize_apply', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')), offset,
                                  _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS,
                                  _p(bn['mean']), _p(bn['invstd']), 1 if update_running else 0, _p(raw), res, out, act, code, lane=lane)
@@ -353,14 +369,14 @@ class EncoderRunner:
                     # the activated tensor is written on the side lane after the encoder (below)
                     deferred.append((raw, bn, offset, self.act[op.dst], M, c, ACT_CODES[op.act]))
                 elif fa is None:
-                    apply(None, _p(self.act[op.dst]), ACT_CODES[op.act], ln)
+                    apply(None, _p(self.act[op.dst]), ACT_CODES[op.act], ln, op.dst)
                     if ln:
                         plan.record(('fout', op.dst), 1)
                         side_out.add(op.dst)
                 else:
                     if fa.a in side_out:
                         plan.wait(('fout', fa.a), 0)
-                    apply(_p(self.act[fa.a]), _p(self.act[fa.dst]), ACT_CODES[fa.act], 0)
+                    apply(_p(self.act[fa.a]), _p(self.act[fa.dst]), ACT_CODES[fa.act], 0, fa.dst)
             elif isinstance(op, arch.Add):
                 n = self.act[op.dst].numel()
                 plan.add('capmi_add_act', _p(self.act[op.a]), _p(self.act[op.b]), _p(self.act[op.dst]), n, ACT_CODES[op.act], code)
@@ -621,6 +637,8 @@ class EncoderRunner:
                     addend = dx if t in written else pending.pop(t, None)
                     mask = is_last and covered and src_act is not None
                     ysaved, dact = (_p(self.act[t]), ACT_CODES[src_act]) if mask else (None, 0)
+                    if mask and t in self.maskbits:         # the bit mask of the forward pass instead of the tensor itself
+                        ysaved, dact = _p(self.maskbits[t]), dact | DACT_BITMASK
                     # this launch completes grad[t] in its final (pre-activation) form: take the BN backward
                     # sums of the layers that consume it in the same epilogue
                     targets = bnred_targets(t) if (self.fuse_bn_reduce and is_last and covered and (mask or src_act is None)) else []

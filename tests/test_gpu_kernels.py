@@ -667,6 +667,57 @@ def test_conv_with_inference_batch_norm_in_the_epilogue(dtype, B, C, H, W, Co, k
     assert float(d) <= tol * max(1.0, float(Y2.float().abs().max())), float(d)
 
 
+@pytest.mark.parametrize('act,res', [('relu', False), ('relu', True), ('relu6', False)])
+@pytest.mark.parametrize('B,C,H,W,Cn,k', [(4, 64, 56, 56, 256, 1),       # 128 x 128 tiles
+                                            (8, 256, 14, 14, 64, 1),       # 64 x 64 tiles
+                                            (8, 256, 56, 56, 64, 1),       # 128 x 64 tiles (tall grid)
+                                            (8, 128, 28, 28, 128, 3),      # halo kernel
+                                            (16, 512, 7, 7, 512, 3),       # k-group kernel
+                                            (3, 40, 9, 11, 72, 3),         # ragged rows, N = 72
+                                            (64, 1024, 14, 14, 256, 1)])   # 128 x 128 k-group tiles
+def test_activation_bit_mask_in_the_data_gradient_epilogue(act, res, B, C, H, W, Cn, k):
+    """capmi_bn_apply_mask writes y (== capmi_bn_apply, bit for bit) and one bit per element, act'(y) == 1 at the STORED output;
+    a data-gradient launch that takes the bit mask (dact | CAPMI_DACT_BITMASK) must equal the launch that reads y itself, bit
+    for bit (conv2d_grad under a ReLU: the mask of MobileNetV2.py:112-121's activation), with and without an addend."""
+    _lib, tdt, code = _env()
+    dtype = 'bf16'
+    rng = np.random.RandomState(C + Cn + k + B)
+    f32 = torch.float32
+    M = B * H * W
+    raw = dev(rng.standard_normal((B, H, W, Cn)) * 1.3 + 0.2, tdt[dtype])
+    mean, ca = dev(rng.standard_normal(Cn) * 0.2, f32), dev(rng.uniform(0.5, 1.5, Cn), f32)
+    off = dev(rng.standard_normal(Cn) * (2.0 if act == 'relu6' else 0.3) + (3.0 if act == 'relu6' else 0.0), f32)
+    R = dev(rng.standard_normal((B, H, W, Cn)), tdt[dtype]) if res else None
+    ac = _lib.ACT_CODES[act]
+    Y0 = torch.zeros((B, H, W, Cn), dtype=tdt[dtype], device=DEV)
+    Y1 = torch.zeros((B, H, W, Cn), dtype=tdt[dtype], device=DEV)
+    bits = torch.zeros(M * Cn // 8, dtype=torch.uint8, device=DEV)
+    _lib.call('capmi_bn_apply', p(raw), p(mean), p(ca), p(off), p(R), p(Y0), M, Cn, ac, code[dtype], stream())
+    _lib.call('capmi_bn_apply_mask', p(raw), p(mean), p(ca), p(off), p(R), p(Y1), p(bits), M, Cn, ac, code[dtype], stream())
+    torch.cuda.synchronize()
+    assert torch.equal(Y0, Y1)
+    yf = Y1.float().reshape(M, Cn)
+    want = (yf > 0) if act == 'relu' else ((yf > 0) & (yf < 6))
+    assert 0.05 < float(want.float().mean()) < 0.95          # both values of the bit occur
+    w8 = (want.reshape(M, Cn // 8, 8).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(-1).to(torch.uint8)
+    assert torch.equal(bits.reshape(M, Cn // 8), w8)
+    pad = 1 if k == 3 else 0
+    dy = dev(rng.standard_normal((B, H, W, C)), tdt[dtype])                         # gradient of the conv's output (C channels)
+    wt = dev(rng.standard_normal((Cn, k, k, C)) / np.sqrt(C * k * k), tdt[dtype])   # data-gradient weight form [Cn][kh][kw][C]
+    gd = _lib.ConvGeom(B, H, W, C, H, W, k, k, 1, 1, k - 1 - pad, C)
+    K = k * k * C
+    for with_addend in (False, True):
+        A = dev(rng.standard_normal((B, H, W, Cn)), tdt[dtype]) if with_addend else None
+        D0 = torch.full((B, H, W, Cn), float('nan'), dtype=tdt[dtype], device=DEV)
+        D1 = torch.full((B, H, W, Cn), float('nan'), dtype=tdt[dtype], device=DEV)
+        _KEEP.extend([D0, D1, Y0, Y1, bits])
+        _lib.call('capmi_igemm_nt', p(dy), p(wt), p(D0), gd, Cn, K, Cn, None, p(A), Cn, p(Y1), Cn, None, 0, ac, 0, code[dtype], stream())
+        _lib.call('capmi_igemm_nt', p(dy), p(wt), p(D1), gd, Cn, K, Cn, None, p(A), Cn, p(bits), Cn, None, 0, ac | _lib.DACT_BITMASK, 0, code[dtype], stream())
+        torch.cuda.synchronize()
+        assert torch.equal(D0, D1), int((D0 != D1).sum())
+        assert bool(((D0.float().reshape(M, Cn) == 0) | want).all())             # masked elements are exactly zero
+
+
 @pytest.mark.parametrize('B,C,H,W,Co,k,s', [(4, 64, 56, 56, 256, 1, 1),       # 128 x 128 tiles, K = 64
                                              (4, 256, 56, 56, 64, 1, 1),       # 128 x 64 tiles (tall grid, narrow output)
                                              (8, 128, 28, 28, 128, 3, 1),      # halo kernel
