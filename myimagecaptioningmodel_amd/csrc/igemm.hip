@@ -420,6 +420,36 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
     }
 }
 
+// ------------------------------------------------------------------ mask bytes of the epilogue, fetched in front of the main loop
+// EPI 6 (data gradient with its ReLU mask as bits): the bytes a lane's rows need -- one per row, TM x 4 registers -- are loaded
+// BEFORE the k loop, so the epilogue of a mask-only data gradient issues no load at all (its only memory round trip used to be
+// the mask; a timing run without the mask bounds that at 0.15 ms per step, lesson 53).  Same row / column mapping as nt_epilogue.
+template <typename T, int BM, int BN, int WMW>
+__device__ __forceinline__ void nt_prefetch_mask(const IGemmArgs& a, int m0, int n0, unsigned (&pm)[BM / WMW / 16][4]) {
+    constexpr int WNW = 4 / WMW, RW = BM / WMW, WN = BN / WNW, TM = RW / 16, TN = WN / 16;
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int wrow0 = m0 + wm * RW;
+    const int wcnt = min(RW, a.M - wrow0);
+    const int col0 = n0 + wn * WN + TN * fr;
+    const uint8_t* bits = reinterpret_cast<const uint8_t*>(a.ysaved);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rl = i * 16 + fg * 4 + r;
+            int64_t row = wrow0 + rl;
+            const bool valid = rl < wcnt && col0 < a.N;
+            if (a.g.os > 1 && valid) {
+                const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
+                const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
+                row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
+            }
+            pm[i][r] = valid ? (unsigned)bits[(row * a.ld_saved + col0) >> 3] : 0u;
+        }
+}
+
 // ------------------------------------------------------------------ shared epilogue of the tiled NT kernels
 // DENSE: the host guarantees N and every row pitch the epilogue touches are multiples of 8 (nt_dense): every lane stores whole
 // runs, and the element-wise store path -- HALF of each kernel's instructions, all of them unrolled copies that only ragged
@@ -440,7 +470,8 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
 // (model_adaAttention_aic.py:25), once per train step and once per decode step.
 template <typename T, int BM, int BN, int WMW, bool RED = false, bool DENSE = false, int EPI = 0>
 __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM / WMW / 16][BN / (4 / WMW) / 16], int m0, int n0, float* sred,
-                                            int64_t slab_off = 0) {      // f32 elements added to y (split-K: this split's slab)
+                                            int64_t slab_off = 0,        // f32 elements added to y (split-K: this split's slab)
+                                            const unsigned (*pmask)[4] = nullptr) {      // EPI 6: mask bytes fetched in front of the main loop (nt_prefetch_mask)
     constexpr int WNW = 4 / WMW, RW = BM / WMW, WN = BN / WNW, TM = RW / 16, TN = WN / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WNW, wn = wave % WNW;
@@ -515,7 +546,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 for (int r = h; r < h + RB; ++r) {
                     if (EPI != 1 && EPI != 5 && addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
                     if constexpr (EPI == 6) {
-                        if (valid[r]) py[r][0] = bits_to_elem<T>(reinterpret_cast<const uint8_t*>(a.ysaved)[(rows[r] * a.ld_saved + col0) >> 3]);
+                        if (!pmask && valid[r]) py[r][0] = bits_to_elem<T>(reinterpret_cast<const uint8_t*>(a.ysaved)[(rows[r] * a.ld_saved + col0) >> 3]);
                     } else if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
                     if (RED && valid[r]) px[r] = *reinterpret_cast<const RunT*>(rx0 + rows[r] * a.N + col0);
                 }
@@ -544,7 +575,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                         }
                     }
                     if constexpr (EPI == 6) {
-                        const unsigned m = elem_to_bits<T>(py[r][0]) >> (col0 & 7);
+                        const unsigned m = (pmask ? pmask[i][r] : elem_to_bits<T>(py[r][0])) >> (col0 & 7);
 #pragma unroll
                         for (int j = 0; j < TN; ++j) v[j] = ((m >> j) & 1u) ? v[j] : 0.f;
                     } else if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact) {
@@ -988,6 +1019,12 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
         boff[j] = AOPB + row * 64 + ((fg ^ lds_swz4(row >> 2)) << 4);
     }
 
+    // EPI 6: the epilogue's mask bytes, loaded now (in FRONT of the DMA issues: vector-memory operations retire in order, so the
+    // loop's counted waits stay exact) and consumed after the loop
+    unsigned pmask[TM][4];
+    if constexpr (EPI == 6) {
+        if (grp == 0) nt_prefetch_mask<T, BM, BN, WMW>(a, m0, n0, pmask);
+    }
     // CAPMI_NT_ABL (tools/nt_ablate.hip only, 0 in the library): 1 = no MFMAs, 2 = no LDS reads either, 4 = no DMA
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p)
@@ -1056,7 +1093,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] += xch[(g * TM * TN + i * TN + j) * 256 + tid];
     }
-    nt_epilogue<T, BM, BN, WMW, RED, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem), (int64_t)split * a.M * a.ldy);
+    nt_epilogue<T, BM, BN, WMW, RED, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem), (int64_t)split * a.M * a.ldy, EPI == 6 ? pmask : nullptr);
 }
 
 template <int BM, int BN, int NST, bool RED = false, int LIN = 0, int EPI = 0>
@@ -1202,6 +1239,8 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
         inbn_load_table<INBN_KMAX>(inbn_tab, a, Cin, tid);
         __syncthreads();
     }
+    unsigned pmask[TM][4];                                      // EPI 6: the epilogue's mask bytes, in front of the DMA issues (see nt_glds_body)
+    if constexpr (EPI == 6) nt_prefetch_mask<T, BM, BN, WMW>(a, m0, n0, pmask);
     // prologue: halo of chunk 0, filter tiles of steps 0 and 1 (taps 0 and 1 of chunk 0)
     issue_A(0, 0, true);
     issue_B(0, 0, true);
@@ -1295,7 +1334,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // retire the (zero-page) tail issues before LDS reuse
     __syncthreads();
-    nt_epilogue<T, BM, BN, WMW, false, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem));
+    nt_epilogue<T, BM, BN, WMW, false, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem), 0, EPI == 6 ? pmask : nullptr);
 }
 
 // Several independent problems (the parity classes of a strided data gradient) in ONE launch: the
@@ -2545,7 +2584,7 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
             const bool skinny = nt_uses_skinny(&c.g, a.M, a.K, false, dtype);
             const NtCfg cfg = nt_cfg(a.M, a.N, a.K, dtype);
             fuse128 = fuse128 && !skinny && cfg.bn == 128 && cfg.wmw == 4 && nt_dense(a);
-            fuse64 = fuse64 && !skinny && cfg.wmw == 5 && !nt_halo3_ok(a, &c.g, 0) && nt_dense(a) && !nt_bits_class(a);      // (no 64-wide group kernel reads mask bits)
+            fuse64 = fuse64 && !skinny && cfg.wmw == 5 && !nt_halo3_ok(a, &c.g, 0) && nt_dense(a);
             conv1 = conv1 && c.g.up == 1 && c.g.Cin >= 32;
             lin = lin && c.g.kh == 1 && c.g.kw == 1 && c.g.up == 1 && c.g.pad == 0 && (c.g.Ho - 1) * c.g.sd < c.g.Hi && (c.g.Wo - 1) * c.g.sd < c.g.Wi;
             blocks128 += ((long long)cdiv(a.M, 64) * cdiv(a.N, 128) + 7) / 8 * 8;      // ranges start at multiples of 8 (XCD order)
@@ -2577,6 +2616,9 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
             } else if (fuse128) {
                 if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
                 else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+            } else if (allbits) {           // (the same tile as without the bits: the kernel choice must not depend on the mask's form)
+                if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (fc && lin) {         // the decode step's grouped projections (bias, tanh)
                 hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (cc) {

@@ -352,6 +352,38 @@ def test_engine_with_persistent_recurrence_equals_per_step_plan(layers, monkeypa
 
 
 # ------------------------------------------------------------------ batch norm in the consumer's operand path, inside the engine
+def test_relu_masks_as_bits_in_the_engine_are_bit_identical(monkeypatch, deterministic):
+    """CAPMI_MASKBITS=1 (default: capmi_bn_apply_mask writes one bit per element of every ReLU tensor in the forward pass, the data
+    gradient that masks the tensor's gradient reads the bits in front of its main loop -- igemm.hip EPI 6) against CAPMI_MASKBITS=0
+    (the epilogue reads the saved output itself): the same loss, every activation gradient and every parameter gradient BIT FOR BIT
+    (deterministic mode), and the bits equal y > 0 of the stored tensors (conv2d_grad under relu, MobileNetV2.py:112-121)."""
+    ocfg, ecfg = _cfgs('resnet50', 'slots', 'bf16', S=128)
+    B = 8
+    params, image, caption = _data(ocfg, B, seed=4)
+    out = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('CAPMI_MASKBITS', mode)
+        eng = _engine(ecfg, params)
+        loss = float(eng.forward_backward(image, caption).cpu()[0])
+        torch.cuda.synchronize()
+        prog = eng._train[B]
+        enc = prog['enc']
+        out[mode] = dict(loss=loss, grads=eng.export_reference_grads(), g={k: v.clone() for k, v in enc.grad.items()},
+                         act={k: v.clone() for k, v in enc.act.items()}, bits={k: v.clone() for k, v in enc.maskbits.items()},
+                         calls=[c[1] for c in prog['fwd'].calls if c[0] is not None])
+    a, b = out['0'], out['1']
+    assert len(a['bits']) == 0 and len(b['bits']) >= 40 and b['calls'].count('capmi_bn_apply_mask') == len(b['bits'])
+    assert a['loss'] == b['loss']
+    for k in a['g']:
+        assert torch.equal(a['g'][k], b['g'][k]), ('activation gradient', k)
+    for n, g in a['grads'].items():
+        np.testing.assert_array_equal(b['grads'][n], g, err_msg=n)
+    for k, bits in b['bits'].items():
+        y = b['act'][k].float().reshape(-1, 8)
+        want = ((y > 0).to(torch.int32) << torch.arange(8, device=y.device, dtype=torch.int32)).sum(-1).to(torch.uint8)
+        assert torch.equal(want, bits), ('mask bits of tensor', k)
+
+
 @pytest.mark.parametrize('level', [1, 2])
 def test_operand_path_batch_norm_in_the_engine_is_bit_identical(level, monkeypatch, deterministic):
     """CAPMI_INBN=1 / 2 (capmi_igemm_nt_bnact on the 1x1 / also the halo-staged 3x3 consumers, the producers' bn_apply moved
