@@ -2086,8 +2086,7 @@ static NtCfg nt_cfg(int M, int N, int K, int dtype) {
             const bool big = K >= big_k && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= big_tiles;   // LDS-DMA pipeline kernel: full grid
             const int64_t t128 = (int64_t)cdiv(M, 128) * cdiv(N, 128);
             if (!big && K >= 1024 && t128 >= 160 && t128 <= 256) return NtCfg{128, 128, 4};      // one round of 128x128 tiles, two k-groups each
-            static const int small_tiles = getenv("CAPMI_NT_SMALLTILES") ? atoi(getenv("CAPMI_NT_SMALLTILES")) : 256;      // experiment knob
-            if (!big && (int64_t)cdiv(M, 64) * cdiv(N, 128) < small_tiles) return NtCfg{64, 64, 5};      // under-filled grid: 64x64 LDS-DMA tiles (wmw 5 = marker)
+            if (!big && (int64_t)cdiv(M, 64) * cdiv(N, 128) < 256) return NtCfg{64, 64, 5};      // under-filled grid: 64x64 LDS-DMA tiles (wmw 5 = marker)
             return NtCfg{big ? 128 : 64, 128, 4};
         }
         // tall grids of narrow outputs (the 64-channel 56 x 56 layers): 128 x 64 tiles pay the prologue, the statistics and (3 x 3)

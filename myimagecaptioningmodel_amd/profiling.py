@@ -34,7 +34,7 @@ def _nt_tile(M, N, K, bf16):
             big = K >= int(os.environ.get('CAPMI_NT_BIGK', '64')) and cd(M, 128) * cd(N, 128) >= int(os.environ.get('CAPMI_NT_BIGTILES', '384'))
             if not big and K >= 1024 and 160 <= cd(M, 128) * cd(N, 128) <= 256:
                 return (128, 128, True)
-            if not big and cd(M, 64) * cd(N, 128) < int(os.environ.get('CAPMI_NT_SMALLTILES', '256')):
+            if not big and cd(M, 64) * cd(N, 128) < 256:
                 return (64, 64, True)
             return (128 if big else 64, 128, True)
         if N >= 32:
