@@ -47,12 +47,12 @@ def synthetic_batch(B, cfg, seed):
     return image, cap
 
 
-def pmc_traffic(label):
-    """HBM bytes per launch of `label` from the newest committed PMC pass (profiles/rNN_pmc_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  PMC
-    counters cannot be read inside this process, so the value comes from a SEPARATE profile pass of the same command;
-    returns (MB per launch or None, source) -- source names the file and the tree it was recorded on, and the value is
-    None when the kernel symbol is missing or matched by more than one row (a renamed or re-tiled kernel)."""
+def pmc_traffic(symbol):
+    """HBM bytes per launch of the kernel `symbol` (the exact rocprofv3 row) from the newest committed PMC pass
+    (profiles/rNN_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read inside this process, so the value comes from a
+    SEPARATE profile pass of the same command; returns (MB per launch or None, source) -- source names the file and the tree it
+    was recorded on, and the value is None when the symbol has no row there or the kernels changed since."""
     import glob
     import re
     files = glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json'))
@@ -62,24 +62,10 @@ def pmc_traffic(label):
         return None, None
     with open(files[-1]) as fh:
         doc = json.load(fh)
-    kernels = doc['kernels']
     source = dict(file=os.path.relpath(files[-1], ROOT), recorded_on=doc.get('head'), pass_='separate rocprofv3 --pmc runs of bench.py')
-    m = re.match(r'(igemm_(nt|tn)_kernel)<(bf16|f32),(\d+),(\d+)>', label)
-    g = re.match(r'igemm_nt_glds_kernel<(\d+),(\d+)>', label)
-    if m:
-        pre = '_Z15%sI%sLi%sELi%sE' % (m.group(1), 'DF16b' if m.group(3) == 'bf16' else 'f', m.group(4), m.group(5))
-        hit = [v for k, v in kernels.items() if k.startswith(pre) or k.replace(' ', '').startswith('void' + label.replace('bf16', '__hip_bfloat16')[:-1])]
-    elif g:
-        hit = [v for k, v in kernels.items() if ('igemm_nt_glds_kernel<%s, %s,' % (g.group(1), g.group(2))) in k
-               or k.startswith('_Z20igemm_nt_glds_kernelILi%sELi%sE' % (g.group(1), g.group(2)))]
-    else:
-        hit = [v for k, v in kernels.items() if re.search(r'\b%s\b' % re.escape(label), k)]
-    if g and len(hit) > 1:
-        # one label = every instantiation of that tile (addressing mode, epilogue class): launch-weighted mean over them
-        n = sum(v['launches'] for v in hit)
-        hit = [dict(hbm_bytes_per_launch=sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hit) / max(n, 1))]
-        source['rows'] = 'launch-weighted mean over the instantiations of this tile'
-    if len(hit) != 1:
+    row = doc['kernels'].get(symbol)
+    if row is None:
+        source['missing'] = 'no row for this symbol'
         return None, source
     # stale profile: the kernels changed since the pass was recorded (checkable only where the git history is present --
     # on the GPU box the snapshot has none, there the recorded head is all that can be reported)
@@ -90,7 +76,29 @@ def pmc_traffic(label):
         if rc != 0:
             source['stale'] = 'csrc/ differs from the tree the pass was recorded on'
             return None, source
-    return round(hit[0]['hbm_bytes_per_launch'] / 1e6, 3), source
+    return round(row['hbm_bytes_per_launch'] / 1e6, 3), source
+
+
+def roofline_of(symbol, s, steps):
+    """Both roofline fractions of one kernel symbol from its in-model time: against HBM (algorithmic bytes) and -- for a GEMM --
+    against the dense bf16 MFMA peak (algorithmic flops).  `bound` names the roof the kernel's intensity puts it under (the
+    bf16 ridge is 2.5 PF / 8 TB/s = 312 flop/B) and `frac` is the fraction against THAT roof; `frac_hbm` / `frac_mfma` are
+    always both there."""
+    from myimagecaptioningmodel_amd import profiling
+    sec = s['ms'] * 1e-3
+    gbps = s['bytes'] / sec / 1e9
+    tflops = s['flops'] / sec / 1e12
+    r = dict(kernel=symbol, frac_hbm=round(gbps / profiling.PEAK_HBM_GBPS, 4),
+             frac_mfma=round(tflops / profiling.PEAK_MFMA_TFLOPS['bf16'], 4) if s['flops'] > 0 else None,
+             achieved_gbps=round(gbps, 1), achieved_tflops=round(tflops, 2) if s['flops'] > 0 else None,
+             avg_launch_us=round(s['ms'] / s['launches'] * 1e3, 2), launches_per_step=round(s['launches'] / steps, 1),
+             ms_per_step=round(s['ms'] / steps, 3), lanes=sorted(s['lanes']),
+             algorithmic_per_launch={'GFLOP': round(s['flops'] / s['launches'] / 1e9, 3), 'MB': round(s['bytes'] / s['launches'] / 1e6, 3)})
+    if s['flops'] > 0 and s['flops'] / max(s['bytes'], 1) > 312:
+        r.update(bound='mfma', achieved=r['achieved_tflops'], peak=profiling.PEAK_MFMA_TFLOPS['bf16'], unit='TFLOP/s', frac=r['frac_mfma'])
+    else:
+        r.update(bound='hbm', achieved=r['achieved_gbps'], peak=profiling.PEAK_HBM_GBPS, unit='GB/s', frac=r['frac_hbm'])
+    return r
 
 
 def host_cores():
@@ -421,35 +429,37 @@ def main():
                        'precision_note': 'bf16 storage / f32 accumulate: the bf16 engine is held to |loss - oracle| <= 5e-2 (tests); north_star\'s 1e-3 is met by the f32 engine'},
             'final_loss': round(final_loss, 4),
         }
-    # ---- roofline of the dominant kernel: per-launch HIP-event timing of one eager step (rank 0, N = 1 only)
+    # ---- roofline of the dominant kernel: HIP-event timing of every launch of the step ON ITS LANE (rank 0, N = 1 only)
     if rank == 0 and world == 1 and not args.no_roofline:
-        progress('%.2f ms/step; per-launch HIP-event pass for the roofline line' % (dt / args.steps * 1e3))
+        progress('%.2f ms/step; in-model HIP-event pass (two lanes) for the roofline line' % (dt / args.steps * 1e3))
         prog = eng._train[B]
-        stats = {}
-        for plan in (prog['fwd'], prog['bwd']):
-            for k, v in profiling.time_plan(plan, eng._stream(), repeats=2).items():
-                s = stats.setdefault(k, dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
-                for f in s:
-                    s[f] += v[f]
-        total_ms = sum(s['ms'] for s in stats.values())
+        if 'bwd_opt' not in prog:
+            eng._build_fused_bwd(prog)
+        R = 3
+        over = profiling.event_pair_overhead_ms(eng._stream())
+        stats, lane_ms = profiling.time_step([prog['fwd'], prog['bwd_opt']], eng._stream(), repeats=R, overhead_ms=over)
         top = sorted(stats.items(), key=lambda kv: -kv[1]['ms'])
+        # the dominant kernel = the SINGLE kernel symbol with the most in-model time (a row of rocprofv3 --kernel-trace --stats)
         name, s = top[0]
-        if s['flops'] > 0 and s['flops'] / max(s['bytes'], 1) > 300:      # above the bf16 ridge point (2.5 PF / 8 TB/s)
-            achieved = s['flops'] / (s['ms'] * 1e-3) / 1e12
-            peak = profiling.PEAK_MFMA_TFLOPS['bf16']
-            roof = dict(bound='mfma', achieved=round(achieved, 2), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4))
-        else:
-            achieved = s['bytes'] / (s['ms'] * 1e-3) / 1e9
-            roof = dict(bound='hbm', achieved=round(achieved, 1), peak=profiling.PEAK_HBM_GBPS, unit='GB/s',
-                        frac=round(achieved / profiling.PEAK_HBM_GBPS, 4))
+        roof = roofline_of(name, s, R)
         traffic, traffic_src = pmc_traffic(name)
-        roof.update(kernel=name, traffic=traffic, traffic_source=traffic_src, avg_launch_us=round(s['ms'] / s['launches'] * 1e3, 2),
-                    share_of_step=round(s['ms'] / total_ms, 3),
-                    traffic_unit='MB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)',
-                    algorithmic_per_launch={'GFLOP': round(s['flops'] / s['launches'] / 1e9, 3),
-                                            'MB': round(s['bytes'] / s['launches'] / 1e6, 3)})
+        roof.update(traffic=traffic, traffic_source=traffic_src, traffic_unit='MB per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/)',
+                    share_of_kernel_time=round(s['ms'] / sum(v['ms'] for v in stats.values()), 3),
+                    timing='HIP events around every launch on the stream it is launched on, the step running on its two lanes (%d runs); '
+                           'minus the interval an event pair adds by itself, calibrated on an idle device' % R,
+                    event_pair_overhead_us=round(over * 1e3, 2))
         out['roofline'] = roof
-        out['kernel_breakdown_ms_per_step'] = {k: round(v['ms'] / 2, 3) for k, v in top[:8]}
+        gemm = [(k, v) for k, v in top if v['flops'] > 0]
+        # the largest MAIN-lane GEMM symbol next to it (the dominant symbol is a side-lane weight gradient)
+        main_gemm = next(((k, v) for k, v in gemm if 0 in v['lanes'] and k != name), None)
+        if main_gemm is not None:
+            out['roofline_main_lane_gemm'] = roofline_of(main_gemm[0], main_gemm[1], R)
+        g_fl, g_ms = sum(v['flops'] for _, v in gemm), sum(v['ms'] for _, v in gemm)
+        out['gemm_mfma_frac'] = round(g_fl / (g_ms * 1e-3) / 1e12 / profiling.PEAK_MFMA_TFLOPS['bf16'], 4)
+        out['gemm_summary'] = dict(gflop_per_step=round(g_fl / R / 1e9, 1), gemm_kernel_ms_per_step=round(g_ms / R, 3),
+                                   note='sum of the algorithmic flops of every MFMA kernel of the step / the sum of their in-model durations / 2.5 PFLOP/s')
+        out['kernel_breakdown_ms_per_step'] = {k: round(v['ms'] / R, 3) for k, v in top[:10]}
+        out['lane_busy_ms_per_step'] = {str(k): round(v / R, 3) for k, v in sorted(lane_ms.items())}
         flops_img = FLOPS_PER_IMAGE[args.config]          # 6 x forward GEMM-class MACs
         out['model_mfma_frac'] = round(out['value'] * flops_img / (world * profiling.PEAK_MFMA_TFLOPS['bf16'] * 1e12), 4)
     if rank == 0 and world == 1 and not args.no_extras and args.config == 1:

@@ -53,6 +53,16 @@ int capmi_set_deterministic(int on);
 int capmi_general_epilogue(void);
 int capmi_set_general_epilogue(int on);
 
+/* Measurement aid: WHICH kernel would a capmi_igemm_* call launch?  Between capmi_kernel_probe_begin() and
+ * capmi_kernel_probe_end() on one host thread, every capmi_igemm_* / capmi_lstm_* entry point called on that thread goes
+ * through its normal argument checks and kernel selection but RECORDS the kernel instead of launching it (nothing is enqueued,
+ * no memory is touched).  _end closes the probe and returns the symbol of the first kernel of the call as rocprofv3 prints it
+ * (demangled where the C++ ABI demangler can; the mangled name otherwise), its grid (workgroups) and block size, and the
+ * number of kernels the call would have launched.  bench.py labels every GEMM launch of a step this way, so its `roofline.kernel`
+ * is a row of `rocprofv3 --kernel-trace --stats` verbatim and cannot drift from the dispatch code. */
+int capmi_kernel_probe_begin(void);
+int capmi_kernel_probe_end(char* symbol, int symbol_len, int* grid, int* block, int* launches);
+
 /* Alternates.  Four entry points are NOT on the default launch plans: each is a fused form that measured slower than
  * the launches it replaces on the ResNet-50 workload, is kept because it is the faster form at other sizes or the
  * per-step fallback of a fused kernel, and is covered by the same parity tests as the default path:
@@ -66,6 +76,10 @@ int capmi_set_general_epilogue(int on);
  * main lane and the side lane that runs weight gradients).  No timing, no system-scope fence: a default
  * hipEventRecord writes the L2 back for the host's benefit, ~6 us of idle queue each time. */
 int capmi_event_create(void** event);
+/* The same with timing enabled (still no system-scope fence), and the milliseconds between two of them once both have
+ * completed: the per-launch measurements of bench.py's roofline pass, recorded on the lane a kernel is launched on. */
+int capmi_event_create_timed(void** event);
+int capmi_event_elapsed_ms(void* start, void* stop, float* ms);
 int capmi_event_destroy(void* event);
 int capmi_event_record(void* event, void* stream);
 int capmi_stream_wait_event(void* stream, void* event);
@@ -183,6 +197,23 @@ int capmi_igemm_nt_bnred(const void* x, const void* w, void* y, const capmi_conv
                          int nred, const void* rx0, const float* mean0, const float* invstd0, float* ws0,
                          const void* rx1, const float* mean1, const float* invstd1, float* ws1,
                          int dtype, void* stream);
+
+/* The data gradient of a convolution (capmi_igemm_nt with the ReLU mask of the completed tensor as bits: dact carries
+ * CAPMI_DACT_BITMASK, `maskbits` from capmi_bn_apply_mask) that ALSO takes the batch-norm backward sums of the layer whose
+ * output gradient it completes -- fluid's batch_norm_grad reductions (IC/model/MobileNetV2.py:112-119 backward) inside the
+ * conv2d_grad of the consumer.  raw = that layer's conv output [M][N] (the rows of y), mean / invstd its saved statistics:
+ * per channel sum_m dz and sum_m dz * (raw - mean) * invstd, dz = the value stored to y (masked, rounded to bf16 -- what
+ * capmi_bn_bwd_apply_spread reads back).  Default: the sums are ADDED (f32 atomics) to acc_rows[4][2N] -- the accumulator rows
+ * capmi_bn_bwd_apply_spread consumes, zeroed by the caller once per step -- and the layer's capmi_bn_bwd_reduce_spread launch
+ * (two tensor reads on the dependency chain) is not needed.  Deterministic mode (capmi_set_deterministic): per-tile parts into
+ * parts_ws (ceil(M / R) * 2N floats, R = capmi_igemm_nt_bnsum_part_rows) + the fixed-order second stage into red
+ * ([d offset | d scale], as capmi_bn_bwd_reduce leaves it).  R = 0: this shape has no kernel with the sums epilogue (the
+ * register-staged kernel, grouped / strided data gradients) -- launch capmi_igemm_nt + capmi_bn_bwd_reduce_spread.  bf16 only. */
+int capmi_igemm_nt_bnsum_part_rows(const capmi_conv_geom* g, int N, int dtype);
+int capmi_igemm_nt_bnsum(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                         const void* addend, int ld_addend, const void* maskbits, int ld_saved, int dact,
+                         const void* raw, const float* mean, const float* invstd, float* acc_rows, float* parts_ws,
+                         float* red, int dtype, void* stream);
 
 /* dW[n][k] += sum_m dY[m][n] * A(m,k): weight gradient (f32 output; the caller zeroes dW once per
  * step).  The pixel axis is split over workgroups; each split stores its partial tile to the f32
@@ -305,6 +336,23 @@ int capmi_bn_inference_coef_batched(const void* jobs, int njobs, int max_c, floa
 int capmi_bn_finalize_apply(float* ws, int part_rows, int M, int C, const float* scale, const float* offset, float* run_mean,
                             float* run_var, float momentum, float eps, float* saved_mean, float* saved_invstd,
                             int update_running, const void* x, const void* res, void* y, int act, int dtype, void* stream);
+/* conv2d -> batch_norm (train mode) of MobileNetV2.py:99-117 WITHOUT the merge + finalize launch between the convolution and
+ * the normalisation (bf16).  capmi_igemm_nt_stat is capmi_igemm_nt whose epilogue ADDS the per-column sum v and sum v^2 of its
+ * f32 accumulators (f32 atomics) to stat_rows[4][2N], zeroed by the caller once per step; capmi_bn_stat_apply forms
+ * mean / invstd / coef_a from the rows in every workgroup's prologue (one-pass variance, clamped at 0), applies
+ * y = act(coef_a * (x - mean) + offset (+ res)) -- capmi_bn_apply's formula; with `mask` also capmi_bn_apply_mask's bits --
+ * and its first row block writes saved_mean / saved_invstd / coef_a and updates the running statistics (momentum as
+ * capmi_bn_finalize).  Deterministic mode (capmi_set_deterministic) and nothing else switches BOTH entry points to the exact
+ * path: (mean, M2) parts of part_rows = capmi_igemm_nt_stats_part_rows rows into `parts` (the capmi_bn_finalize workspace),
+ * then capmi_bn_finalize + capmi_bn_apply[_mask].  capmi_igemm_nt_stat_supported = 0: the shape has no kernel with the sums
+ * epilogue (narrow or ragged outputs, f32): use capmi_igemm_nt + capmi_bn_finalize + capmi_bn_apply. */
+int capmi_igemm_nt_stat_supported(const capmi_conv_geom* g, int N, int dtype);
+int capmi_igemm_nt_stat(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                        float* parts, float* stat_rows, int dtype, void* stream);
+int capmi_bn_stat_apply(const void* x, float* parts, int part_rows, const float* stat_rows, int M, int C, const float* scale,
+                        const float* offset, float* run_mean, float* run_var, float momentum, float eps, float* saved_mean,
+                        float* saved_invstd, float* coef_a, int update_running, const void* res, void* y, uint8_t* mask, int act,
+                        int dtype, void* stream);
 int capmi_bn_bwd_ws_floats(int M, int C, int dtype);
 int capmi_bn_bwd_reduce(const void* dy, const void* x, const void* y, const float* saved_mean,
                         const float* saved_invstd, float* ws, float* red, int M, int C, int act,

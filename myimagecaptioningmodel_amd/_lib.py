@@ -45,6 +45,9 @@ SIGNATURES = {
     'capmi_igemm_nt_bnact': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     'capmi_igemm_nt_bnfin': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _i, _p],
     'capmi_igemm_nt_bnred': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
+    'capmi_igemm_nt_stat': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _i, _p],
+    'capmi_bn_stat_apply': [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p],
+    'capmi_igemm_nt_bnsum': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     'capmi_igemm_nt_group': [ctypes.POINTER(NtCall), _i, _i, _p],
     'capmi_igemm_nt_splitk': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
     'capmi_igemm_tn_wgrad': [_p, _p, _p, _g, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
@@ -119,6 +122,8 @@ class CapmiError(RuntimeError):
 QUERIES = {
     'capmi_igemm_nt_stats_part_rows': [_i, _i, _i, _i],
     'capmi_igemm_nt_bnred_part_rows': [_g, _i, _i],
+    'capmi_igemm_nt_bnsum_part_rows': [_g, _i, _i],
+    'capmi_igemm_nt_stat_supported': [_g, _i, _i],
     'capmi_igemm_nt_bnact_supported': [_g, _i, _i],
     'capmi_bn_stats_part_rows': [_i, _i, _i],
     'capmi_lstm_step_supported': [_i, _i, _i],
@@ -128,11 +133,15 @@ QUERIES = {
     'capmi_set_deterministic': [_i],
     'capmi_general_epilogue': [],
     'capmi_set_general_epilogue': [_i],
+    'capmi_kernel_probe_begin': [],
+    'capmi_kernel_probe_end': [_p, _i, _p, _p, _p],
 }
 
 # lane synchronisation (no stream-last convention): name -> argument ctypes
 SYNC = {
     'capmi_event_create': [_p],          # void** event
+    'capmi_event_create_timed': [_p],
+    'capmi_event_elapsed_ms': [_p, _p, _p],
     'capmi_event_destroy': [_p],
     'capmi_event_record': [_p, _p],
     'capmi_stream_wait_event': [_p, _p],
@@ -239,6 +248,22 @@ def call(name, *args):
         raise CapmiError('%s failed (%d): %s' % (name, rc, last_error()))
 
 
+def probe_kernel(name, *args):
+    """capmi_kernel_probe_begin / _end around one capmi_igemm_* (or capmi_lstm_*) call: nothing is launched; returns
+    (symbol as rocprofv3 prints it, workgroups, block size, kernels the call launches)."""
+    if not name.startswith(('capmi_igemm_', 'capmi_lstm_')):
+        raise CapmiError('probe_kernel: %s is not a probed entry point' % name)
+    L = lib()
+    buf = ctypes.create_string_buffer(512)
+    grid, block, n = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    L.capmi_kernel_probe_begin()
+    rc = getattr(L, name)(*[a.value if isinstance(a, PtrSlot) else a for a in args], None)
+    rc2 = L.capmi_kernel_probe_end(buf, 512, ctypes.byref(grid), ctypes.byref(block), ctypes.byref(n))
+    if rc != 0 or rc2 != 0:
+        raise CapmiError('probe of %s failed: %s' % (name, last_error()))
+    return buf.value.decode(), grid.value, block.value, n.value
+
+
 WGRAD_WS_BYTES = 32 << 20      # >= any capmi_igemm_tn_ws_bytes() result (partial slabs are capped at 24 MiB)
 _wgrad_ws = {}
 
@@ -313,6 +338,7 @@ class Plan:
     kept for the equivalence test and for debugging a single launch)."""
 
     _side = {}          # device index -> {'streams': {lane: stream}, 'fork': event, 'join': {lane: event}}
+    _timed_events = []  # pool of timing events (run_timed)
 
     def __init__(self):
         self.calls = []
@@ -476,6 +502,67 @@ class Plan:
         for l in others:
             L.capmi_event_record(c['side']['join'][l], ptrs[l])
             L.capmi_stream_wait_event(stream, c['side']['join'][l])
+
+    def run_timed(self, stream):
+        """One eager run of the plan ON ITS LANES with a pair of HIP timing events around every launch, recorded on the
+        stream the launch goes to (`torch.cuda.Event` records on a torch stream object: the lanes are wrapped as
+        ExternalStream).  Returns [(name, args, lane, milliseconds)] in launch order -- the IN-MODEL duration of every kernel
+        (side-lane kernels beside the main lane's and the other way round), which is what `rocprofv3 --kernel-trace` reports
+        for the same step; a single-stream replay times every kernel with the chip to itself.  The event records cost the
+        queues a few microseconds per launch: the step as a whole runs ~10 % slower under it, the kernels themselves do not."""
+        import torch
+        L = lib()
+        lanes = bool(self.has_lanes and os.environ.get('CAPMI_LANES', '1') != '0')
+        c = self._compiled.get(('py', len(self.calls)))
+        if c is None:
+            c = self._compiled[('py', len(self.calls))] = self._compile(True)
+        ptrs = {0: stream}
+        if lanes:
+            ptrs.update({l: s.value for l, s in c['side']['streams'].items()})
+        pool = Plan._timed_events
+
+        def timed_event():
+            if pool:
+                return pool.pop()
+            ev = ctypes.c_void_p()
+            if L.capmi_event_create_timed(ctypes.byref(ev)) != 0:
+                raise CapmiError('capmi_event_create_timed: %s' % last_error())
+            return ev
+        others = [l for l in c['used'] if l] if lanes else []
+        L.capmi_event_record(c['side']['fork'], stream)
+        for l in others:
+            L.capmi_stream_wait_event(ptrs[l], c['side']['fork'])
+        events, seen, timed = c['events'], set(), []
+        for fn, name, args in self.calls:
+            if fn is None:
+                key, lane = args
+                if not lanes:
+                    continue
+                if name == 'record':
+                    seen.add(key)
+                    rc = L.capmi_event_record(events[key], ptrs[lane])
+                else:
+                    rc = L.capmi_stream_wait_event(ptrs[lane], events[key]) if key in seen else 0
+            else:
+                lane = getattr(fn, 'lane', 0) if lanes else 0
+                a, b = timed_event(), timed_event()
+                L.capmi_event_record(a, ptrs[lane])
+                rc = getattr(fn, 'fn', fn)(*[x.value if isinstance(x, PtrSlot) else x for x in args], ptrs[lane])
+                L.capmi_event_record(b, ptrs[lane])
+                timed.append((name, args, lane, a, b))
+            if rc != 0:
+                raise CapmiError('%s failed: %s' % (name, last_error()))
+        for l in others:
+            L.capmi_event_record(c['side']['join'][l], ptrs[l])
+            L.capmi_stream_wait_event(stream, c['side']['join'][l])
+        torch.cuda.synchronize()
+        out, ms = [], ctypes.c_float(0.0)
+        for name, args, lane, a, b in timed:
+            if L.capmi_event_elapsed_ms(a, b, ctypes.byref(ms)) != 0:
+                raise CapmiError('capmi_event_elapsed_ms: %s' % last_error())
+            out.append((name, args, lane, float(ms.value)))
+            pool.extend((a, b))
+        return out
 
     def __len__(self):
         return len(self.calls)

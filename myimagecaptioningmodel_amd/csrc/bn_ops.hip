@@ -457,6 +457,154 @@ extern "C" int capmi_bn_apply_mask(const void* x, const float* saved_mean, const
     return 0;
 }
 
+// ------------------------------------------------------------------ finalize inside the apply launch, from accumulator rows
+// capmi_bn_stat_apply: the statistics arrive as four rows of per-channel (sum v, sum v^2) that the convolution's epilogue added
+// up with f32 atomics (capmi_igemm_nt_stat, igemm.hip EPI 8).  Every workgroup forms mean / invstd / coef_a of ITS channels from
+// the 4 x 2 numbers per channel in its prologue -- the row loads are issued next to the first batch of tensor loads and
+// consumed behind it (as capmi_bn_bwd_apply_spread does: a prologue that waited for them first cost every workgroup one more
+// memory round trip) -- and the first row block also writes saved mean / invstd / coef_a and the running statistics (one
+// writer per channel).  The merge + finalize launch (capmi_bn_finalize: 41 x ~10 us on the forward chain at cfg 2) is gone;
+// unlike capmi_bn_finalize_apply (lesson 30) no workgroup merges parts.  One-pass variance in f32 (var = E[v^2] - mean^2,
+// clamped at 0): relative error ~1e-6 x (1 + mean^2 / var) -- conv outputs have |mean| of the order of their deviation; the
+// f32 engine and deterministic mode keep the exact two-level merge.
+template <int ACT, bool RES, bool MASK>
+__global__ __launch_bounds__(256) void bn_stat_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ rows, float inv_m, const float* __restrict__ scale,
+                                                            const float* __restrict__ offset, float* run_mean, float* run_var, float momentum, float eps,
+                                                            float* saved_mean, float* saved_invstd, float* coef_a, int update_running,
+                                                            const bf16* __restrict__ res, bf16* __restrict__ y, uint8_t* __restrict__ mask, int M, int C, ColLayout L) {
+    typedef bf16 T;
+    constexpr int VEC = 8, U = 4;
+    const int cc = threadIdx.x % L.cpc, rr = threadIdx.x / L.cpc;
+    const int chunk = blockIdx.y * L.cpc + cc;
+    if (rr >= L.rp || chunk * VEC >= C) return;
+    f32x4 t0[4][2], t1[4][2], scv[2], ofv[2], rmv[2], rvv[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            t0[j][q] = *reinterpret_cast<const f32x4*>(rows + (int64_t)j * 2 * C + chunk * VEC + 4 * q);
+            t1[j][q] = *reinterpret_cast<const f32x4*>(rows + (int64_t)j * 2 * C + C + chunk * VEC + 4 * q);
+        }
+    const bool writer = blockIdx.x == 0 && rr == 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        scv[q] = *reinterpret_cast<const f32x4*>(scale + chunk * VEC + 4 * q);
+        ofv[q] = *reinterpret_cast<const f32x4*>(offset + chunk * VEC + 4 * q);
+        if (writer && update_running) {
+            rmv[q] = *reinterpret_cast<const f32x4*>(run_mean + chunk * VEC + 4 * q);
+            rvv[q] = *reinterpret_cast<const f32x4*>(run_var + chunk * VEC + 4 * q);
+        }
+    }
+    const int m_begin = blockIdx.x * L.rows_per_block;
+    const int m_end = min(M, m_begin + L.rows_per_block);
+    const int64_t step = (int64_t)L.rp * C;
+    int m = m_begin + rr;
+    int64_t off = (int64_t)m * C + (int64_t)chunk * VEC;
+    Vec<T> xv[U], rv[U];
+    auto load = [&](int64_t o0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            xv[u] = vload<T>(x + o0 + u * step);
+            if (RES) rv[u] = vload<T>(res + o0 + u * step);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    const bool first = m + (U - 1) * L.rp < m_end;
+    if (first) load(off);
+    float a[VEC], b[VEC], mu[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s0 += t0[j][v / 4][v % 4]; s1 += t1[j][v / 4][v % 4]; }
+        const float mean = s0 * inv_m;
+        const float var = fmaxf(s1 * inv_m - mean * mean, 0.f);      // biased
+        const float invstd = 1.f / sqrtf(var + eps);
+        mu[v] = mean;
+        a[v] = scv[v / 4][v % 4] * invstd;
+        b[v] = ofv[v / 4][v % 4];
+        if (writer) {
+            const int c = chunk * VEC + v;
+            saved_mean[c] = mean;
+            saved_invstd[c] = invstd;
+            coef_a[c] = a[v];
+            if (update_running) {
+                run_mean[c] = rmv[v / 4][v % 4] * momentum + mean * (1.f - momentum);
+                run_var[c] = rvv[v / 4][v % 4] * momentum + var * (1.f - momentum);
+            }
+        }
+    }
+    auto one = [&](const Vec<T>& xi, const Vec<T>& ri, int64_t o) {
+        Vec<T> ov;
+        unsigned bits = 0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            float f = a[v] * (xi.get(v) - mu[v]) + b[v];
+            if (RES) f += ri.get(v);
+            ov.set(v, apply_act(f, ACT));
+            if (MASK) bits |= (act_grad_from_out(ov.get(v), ACT) != 0.f ? 1u : 0u) << v;
+        }
+        if (MASK) mask[o >> 3] = (uint8_t)bits;
+        return ov;
+    };
+    if (first) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) vstore<T>(y + off + u * step, one(xv[u], rv[u], off + u * step));
+        m += U * L.rp;
+        off += U * step;
+    }
+    for (; m + (U - 1) * L.rp < m_end; m += U * L.rp, off += U * step) {
+        load(off);
+#pragma unroll
+        for (int u = 0; u < U; ++u) vstore<T>(y + off + u * step, one(xv[u], rv[u], off + u * step));
+    }
+    for (; m < m_end; m += L.rp, off += step) {
+        Vec<T> xi = vload<T>(x + off), ri;
+        if (RES) ri = vload<T>(res + off);
+        vstore<T>(y + off, one(xi, ri, off));
+    }
+}
+
+/* capmi_bn_finalize + capmi_bn_apply (or capmi_bn_apply_mask when `mask` is given) behind capmi_igemm_nt_stat, as ONE launch:
+ * see capmi.h.  Deterministic mode: the two (three) launches on the exact parts. */
+extern "C" int capmi_bn_stat_apply(const void* x, float* parts, int part_rows, const float* stat_rows, int M, int C, const float* scale,
+                                   const float* offset, float* run_mean, float* run_var, float momentum, float eps, float* saved_mean,
+                                   float* saved_invstd, float* coef_a, int update_running, const void* res, void* y, uint8_t* mask, int act,
+                                   int dtype, void* stream) {
+    CAPMI_CHECK(x && parts && stat_rows && scale && offset && saved_mean && saved_invstd && coef_a && y, "capmi_bn_stat_apply: null pointer");
+    CAPMI_CHECK(!update_running || (run_mean && run_var), "capmi_bn_stat_apply: running stats missing");
+    CAPMI_CHECK(dtype == CAPMI_BF16 && C % 8 == 0, "capmi_bn_stat_apply: bf16 tensors with C %% 8 == 0 only (C=%d dtype=%d)", C, dtype);
+    CAPMI_CHECK(act == CAPMI_ACT_NONE || act == CAPMI_ACT_RELU || act == CAPMI_ACT_RELU6, "capmi_bn_stat_apply: activation %d (none / relu / relu6)", act);
+    CAPMI_CHECK(!mask || act != CAPMI_ACT_NONE, "capmi_bn_stat_apply: the bit mask is for relu / relu6 outputs");
+    CAPMI_CHECK(((uintptr_t)stat_rows | (uintptr_t)scale | (uintptr_t)offset | (uintptr_t)run_mean | (uintptr_t)run_var) % 16 == 0,
+                "capmi_bn_stat_apply: per-channel vectors must be 16-byte aligned");
+    if (capmi_deterministic()) {
+        if (capmi_bn_finalize(parts, part_rows, M, C, scale, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, stream)) return 1;
+        if (mask) return capmi_bn_apply_mask(x, saved_mean, coef_a, offset, res, y, mask, M, C, act, dtype, stream);
+        return capmi_bn_apply(x, saved_mean, coef_a, offset, res, y, M, C, act, dtype, stream);
+    }
+    int gx, gy;
+    ColLayout L = ew_layout(M, C, 8, &gx, &gy);
+    const dim3 grid(gx, gy);
+    hipStream_t st = (hipStream_t)stream;
+    const float inv_m = 1.f / (float)M;
+#define CAPMI_BN_SA(ACT_, RES_, MASK_)                                                                                                          \
+    hipLaunchKernelGGL((bn_stat_apply_kernel<ACT_, RES_, MASK_>), grid, dim3(256), 0, st, (const bf16*)x, stat_rows, inv_m, scale, offset, run_mean, \
+                       run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, (const bf16*)res, (bf16*)y, mask, M, C, L)
+#define CAPMI_BN_SA_ACT(ACT_)                                                                              \
+    do {                                                                                                   \
+        if (mask) { if (res) CAPMI_BN_SA(ACT_, true, true); else CAPMI_BN_SA(ACT_, false, true); }         \
+        else { if (res) CAPMI_BN_SA(ACT_, true, false); else CAPMI_BN_SA(ACT_, false, false); }            \
+    } while (0)
+    if (act == CAPMI_ACT_RELU) CAPMI_BN_SA_ACT(CAPMI_ACT_RELU);
+    else if (act == CAPMI_ACT_RELU6) CAPMI_BN_SA_ACT(CAPMI_ACT_RELU6);
+    else { if (res) CAPMI_BN_SA(CAPMI_ACT_NONE, true, false); else CAPMI_BN_SA(CAPMI_ACT_NONE, false, false); }
+#undef CAPMI_BN_SA_ACT
+#undef CAPMI_BN_SA
+    CAPMI_LAUNCH_CHECK("capmi_bn_stat_apply");
+    return 0;
+}
+
 // ------------------------------------------------------------------ backward
 // Stage 1: every workgroup reduces its row block to partial sums ws[block][2C] (plain stores).
 // Stage 2: red[0..C) += sum dz, red[C..2C) += sum dz*xhat over the partials (fixed order).

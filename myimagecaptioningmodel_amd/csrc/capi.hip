@@ -61,6 +61,23 @@ extern "C" int capmi_event_create(void** event) {
     *event = (void*)ev;
     return 0;
 }
+// Timing events for per-launch measurements (bench.py's roofline pass): device-scope like the lane events -- a default
+// hipEventRecord releases at system scope, i.e. the interval would include the write-back of the kernel's dirty lines and
+// ~6 us of idle queue per record.
+extern "C" int capmi_event_create_timed(void** event) {
+    CAPMI_CHECK(event, "capmi_event_create_timed: null pointer");
+    hipEvent_t ev;
+    hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableSystemFence);
+    CAPMI_CHECK(e == hipSuccess, "capmi_event_create_timed: %s", hipGetErrorString(e));
+    *event = (void*)ev;
+    return 0;
+}
+extern "C" int capmi_event_elapsed_ms(void* start, void* stop, float* ms) {
+    CAPMI_CHECK(start && stop && ms, "capmi_event_elapsed_ms: null pointer");
+    hipError_t e = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    CAPMI_CHECK(e == hipSuccess, "capmi_event_elapsed_ms: %s", hipGetErrorString(e));
+    return 0;
+}
 extern "C" int capmi_event_destroy(void* event) {
     if (event) (void)hipEventDestroy((hipEvent_t)event);
     return 0;

@@ -11,8 +11,72 @@
 #include <stdlib.h>
 #include <atomic>
 
+#include <cxxabi.h>
+
 #include "common.h"
 #include "bn_merge.h"
+
+// ------------------------------------------------------------------ kernel probe (capmi_kernel_probe_begin / _end, capmi.h)
+// Which kernel would this call launch?  Between begin and end every launch site of this file RECORDS its kernel (the first
+// one of a call: the GEMM itself, not the slab reduce behind it) instead of launching it, so the answer comes from the
+// dispatch code itself -- bench.py / profiling.py label a launch with the exact symbol rocprofv3 prints for it, and no Python
+// mirror of nt_cfg() / launch_glds() / launch_tn() can drift from them (round-3 review: profiling._nt_tile did).
+struct KernelProbe {
+    const void* fn;
+    unsigned grid, block;
+    int launches;
+};
+static thread_local KernelProbe* t_probe = nullptr;
+static thread_local KernelProbe t_probe_store;
+static inline void probe_note(const void* fn, dim3 grid, dim3 block) {
+    if (t_probe->launches++ == 0) {
+        t_probe->fn = fn;
+        t_probe->grid = grid.x * grid.y * grid.z;
+        t_probe->block = block.x * block.y * block.z;
+    }
+}
+#define CAPMI_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                              \
+    do {                                                                                                    \
+        if (t_probe) probe_note(reinterpret_cast<const void*>(kernel), dim3(grid), dim3(block));            \
+        else hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                           \
+    } while (0)
+#undef CAPMI_LAUNCH_CHECK
+#define CAPMI_LAUNCH_CHECK(name)                                                           \
+    do {                                                                                   \
+        if (!t_probe) {                                                                    \
+            hipError_t e__ = hipGetLastError();                                            \
+            if (e__ != hipSuccess) {                                                       \
+                capmi_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));    \
+                return 2;                                                                  \
+            }                                                                              \
+        }                                                                                  \
+    } while (0)
+extern "C" int capmi_kernel_probe_begin(void) {
+    t_probe_store = KernelProbe{nullptr, 0u, 0u, 0};
+    t_probe = &t_probe_store;
+    return 0;
+}
+extern "C" int capmi_kernel_probe_end(char* symbol, int symbol_len, int* grid, int* block, int* launches) {
+    KernelProbe* p = t_probe;
+    t_probe = nullptr;
+    CAPMI_CHECK(p, "capmi_kernel_probe_end: no probe is open on this thread");
+    if (grid) *grid = (int)p->grid;
+    if (block) *block = (int)p->block;
+    if (launches) *launches = p->launches;
+    if (symbol && symbol_len > 0) {
+        symbol[0] = 0;
+        if (p->fn) {
+            const char* mangled = hipKernelNameRefByPtr(p->fn, nullptr);
+            (void)hipGetLastError();
+            if (!mangled) return 0;          // (a box without a HIP device: the selection ran, the runtime has no code object to name)
+            int status = 0;
+            char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);        // what rocprofv3 prints (mangled where this fails too)
+            snprintf(symbol, (size_t)symbol_len, "%s", (status == 0 && dem) ? dem : mangled);
+            free(dem);
+        }
+    }
+    return 0;
+}
 
 // floor(n / d) as (n * ceil(2^40 / d)) >> 40, exact whenever n * d < 2^40 (checked by the launchers):
 // one 64-bit multiply instead of a ~40-instruction integer division.
@@ -53,6 +117,9 @@ struct IGemmArgs {
     // fused batch-norm backward reduction (data-gradient launches): for each of `nred` layers that take
     // this launch's OUTPUT as their dy, per-workgroup column sums of dz and dz*(x-mean)*invstd
     int nred;
+    int stat_sums;                   // EPI 8 (capmi_igemm_nt_stat): stats = the layer's accumulator rows [4][2N] of (sum v, sum v^2), added with f32 atomics
+    int red_mode;                    // 0: the RED template path (capmi_igemm_nt_bnred: per-tile parts, up to two targets); 1 / 2: EPI 7 (capmi_igemm_nt_bnsum), ONE
+                                     // target, its sums as f32 atomics into the four accumulator rows rws[0][4][2N] (1) or as per-tile parts rws[0][tile][2][N] (2)
     const void* rx[2];               // the layer's conv output [rows][N], same row indexing as y
     const float* rmean[2];
     const float* rinv[2];
@@ -424,7 +491,7 @@ __device__ __forceinline__ void nt_fin_tail(const IGemmArgs& a, int m0, int n0, 
 // EPI 6 (data gradient with its ReLU mask as bits): the bytes a lane's rows need -- one per row, TM x 4 registers -- are loaded
 // BEFORE the k loop, so the epilogue of a mask-only data gradient issues no load at all (its only memory round trip used to be
 // the mask; a timing run without the mask bounds that at 0.15 ms per step, lesson 53).  Same row / column mapping as nt_epilogue.
-template <typename T, int BM, int BN, int WMW>
+template <typename T, int BM, int BN, int WMW, bool SCATTER = true>
 __device__ __forceinline__ void nt_prefetch_mask(const IGemmArgs& a, int m0, int n0, unsigned (&pm)[BM / WMW / 16][4]) {
     constexpr int WNW = 4 / WMW, RW = BM / WMW, WN = BN / WNW, TM = RW / 16, TN = WN / 16;
     const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -441,7 +508,7 @@ __device__ __forceinline__ void nt_prefetch_mask(const IGemmArgs& a, int m0, int
             const int rl = i * 16 + fg * 4 + r;
             int64_t row = wrow0 + rl;
             const bool valid = rl < wcnt && col0 < a.N;
-            if (a.g.os > 1 && valid) {
+            if (SCATTER && a.g.os > 1 && valid) {
                 const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
                 const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
                 row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
@@ -466,6 +533,19 @@ __device__ __forceinline__ void nt_prefetch_mask(const IGemmArgs& a, int m0, int
 // addend, relu / relu6 or nothing, storage-type output; no statistics, no derivative mask.
 // EPI = 6: the data-gradient form (4) whose ReLU mask comes as BITS (dact | CAPMI_DACT_BITMASK: a byte per 8 channels that
 // capmi_bn_apply_mask wrote in the forward pass) instead of the saved activation itself -- 1/16 of the mask's bytes.
+// EPI = 7 (capmi_igemm_nt_bnsum): EPI 6 + the batch-norm BACKWARD sums of the layer whose output gradient this launch completes
+// (sum dz and sum dz * (x - mean) * invstd per column, x = that layer's conv output): the epilogue loads the x run of every row
+// next to the addend, adds the masked, bf16-rounded gradient -- the very values bn_bwd_apply will read back -- into 2 x TN
+// per-lane sums, folds them over the wave (row4_sum), over the four waves in LDS, and sends 2 x BN f32 atomics per workgroup to
+// the layer's accumulator rows (capmi_bn_bwd_reduce_spread's layout; deterministic mode: plain stores of per-tile parts).  The
+// streaming reduction of that layer (a launch + two tensor reads on the dependency chain) is gone.  One target, no statistics,
+// mask bits always prefetched; instantiated only for the launches that carry it (lesson 54).
+// EPI = 8 (capmi_igemm_nt_stat): the forward form (1) whose batch statistics leave the workgroup as SUMS -- sum v and sum v^2 per
+// column from the f32 accumulators, folded over the wave and the four waves like EPI 7's, 2 x BN f32 atomics per workgroup into
+// the layer's four accumulator rows stats[4][2N] -- instead of one exact (mean, M2) part per row block.  capmi_bn_stat_apply
+// forms mean / invstd from the rows in its prologue: the merge + finalize launch behind every convolution of the forward chain
+// (41 x ~10 us at cfg 2) is gone.  Not bit-reproducible (atomic order) and one-pass in f32: bf16 engines outside deterministic
+// mode only -- the f32 engine and deterministic mode keep the exact parts.
 // EPI = 5 (nt_f32_class): a plain product with an f32 output and at most a bias -- the vocabulary projection's logits
 // (model_adaAttention_aic.py:25), once per train step and once per decode step.
 template <typename T, int BM, int BN, int WMW, bool RED = false, bool DENSE = false, int EPI = 0>
@@ -510,13 +590,29 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
     // two BN layers.  Target 0's sums are taken while the rows are stored; target 1 (rare) in a later pass.
     const T* rx0 = (const T*)a.rx[0];
     float mu0[TN], s1[TN], s2[TN];
-    if constexpr (RED) {
+    if constexpr (RED || EPI == 7) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const bool ok = col0 + j < a.N;
             mu0[j] = ok ? a.rmean[0][col0 + j] : 0.f;
             s1[j] = 0.f; s2[j] = 0.f;
         }
+    }
+    // EPI 7: the batch-norm operand (the layer's conv output) of EVERY row of the lane, requested up front -- the fragment
+    // registers of the main loop are dead by now -- so the epilogue pays one memory latency for them, not one per row batch
+    // (measured: +10.7 us per launch with the loads inside the batches, 2 rows at a time)
+    RunT pxa[EPI == 7 ? TM : 1][4];
+    if constexpr (EPI == 7) {
+        if (col0 < a.N) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int rl = i * 16 + fg * 4 + r;
+                    if (rows_full || rl < wcnt) pxa[i][r] = *reinterpret_cast<const RunT*>(rx0 + (int64_t)(wrow0 + rl) * a.N + col0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     if (col0 < a.N) {
 #pragma unroll
@@ -528,7 +624,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 const int rl = i * 16 + fg * 4 + r;
                 valid[r] = rows_full || rl < wcnt;
                 int64_t row = wrow0 + rl;
-                if (EPI != 1 && a.g.os > 1 && valid[r]) {  // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
+                if (EPI != 1 && EPI != 8 && EPI != 7 && a.g.os > 1 && valid[r]) {  // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
                     const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
                     const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
                     row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
@@ -544,10 +640,10 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 RunT pa[4], py[4], px[4];
 #pragma unroll
                 for (int r = h; r < h + RB; ++r) {
-                    if (EPI != 1 && EPI != 5 && addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
+                    if (EPI != 1 && EPI != 8 && EPI != 5 && addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
                     if constexpr (EPI == 6) {
                         if (!pmask && valid[r]) py[r][0] = bits_to_elem<T>(reinterpret_cast<const uint8_t*>(a.ysaved)[(rows[r] * a.ld_saved + col0) >> 3]);
-                    } else if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
+                    } else if (EPI != 7 && EPI != 1 && EPI != 8 && EPI != 3 && EPI != 5 && a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
                     if (RED && valid[r]) px[r] = *reinterpret_cast<const RunT*>(rx0 + rows[r] * a.N + col0);
                 }
 #pragma unroll
@@ -556,7 +652,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                     float v[TN], t[TN];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
-                    if (EPI != 1 && EPI != 5 && addend) {
+                    if (EPI != 1 && EPI != 8 && EPI != 5 && addend) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) v[j] += (float)pa[r][j];
                     }
@@ -578,7 +674,11 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                         const unsigned m = (pmask ? pmask[i][r] : elem_to_bits<T>(py[r][0])) >> (col0 & 7);
 #pragma unroll
                         for (int j = 0; j < TN; ++j) v[j] = ((m >> j) & 1u) ? v[j] : 0.f;
-                    } else if (EPI != 1 && EPI != 3 && EPI != 5 && a.dact) {
+                    } else if constexpr (EPI == 7) {
+                        const unsigned m = pmask[i][r] >> (col0 & 7);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) v[j] = ((m >> j) & 1u) ? v[j] : 0.f;
+                    } else if (EPI != 1 && EPI != 8 && EPI != 3 && EPI != 5 && a.dact) {
 #pragma unroll
                         for (int j = 0; j < TN; ++j) t[j] = (float)py[r][j];
                         if constexpr (EPI == 0) dact_run<TN>(v, t, a.dact);
@@ -600,6 +700,14 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                             acc[i][j][r] = dz;
                             s1[j] += dz;
                             s2[j] += dz * ((float)px[r][j] - mu0[j]);      // * invstd when the part is written
+                        }
+                    }
+                    if constexpr (EPI == 7) {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float dz = to_f32(from_f32<T>(v[j]));     // the value the BN apply pass reads back
+                            s1[j] += dz;
+                            s2[j] += dz * ((float)pxa[i][r][j] - mu0[j]);  // * invstd below, once per column
                         }
                     }
                 }
@@ -640,6 +748,36 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                     }
                 }
             }
+        }
+    }
+    if constexpr (EPI == 8) {
+        // rows past M multiplied the zero page: their accumulators are exactly 0 and add nothing to either sum
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s1 += acc[i][j][r];
+                    s2 += acc[i][j][r] * acc[i][j][r];
+                }
+            const float r1 = row4_sum(s1), r2 = row4_sum(s2);
+            if (fg == 0) {
+                const int c = wn * WN + TN * fr + j;
+                sred[(wm * BN + c) * 2 + 0] = r1;
+                sred[(wm * BN + c) * 2 + 1] = r2;
+            }
+        }
+        lds_barrier();
+        if (tid < BN && n0 + tid < a.N && m0 < a.M) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) { t1 += sred[(w * BN + tid) * 2]; t2 += sred[(w * BN + tid) * 2 + 1]; }
+            float* row = a.stats + (int64_t)((m0 / BM) & 3) * 2 * a.N + n0 + tid;
+            __hip_atomic_fetch_add(row, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(row + a.N, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (EPI <= 1 && a.stats) {      // (EPI 2 / 3 / 4 never carry statistics)
@@ -706,6 +844,35 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
             }
         }
         if (CAPMI_FIN && a.fin_cnt) nt_fin_tail<BM, BN>(a, m0, n0, sred);
+    }
+    if constexpr (EPI == 7) {
+        // (first barrier: every wave is done with whatever lived at the start of the staging area -- the k-group exchange)
+        lds_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float r1 = row4_sum(s1[j]), r2 = row4_sum(s2[j]);
+            if (fg == 0) {
+                const int c = wn * WN + TN * fr + j;
+                sred[(wm * BN + c) * 2 + 0] = r1;
+                sred[(wm * BN + c) * 2 + 1] = r2;
+            }
+        }
+        lds_barrier();
+        if (tid < BN && n0 + tid < a.N && m0 < a.M) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WMW; ++w) { t1 += sred[(w * BN + tid) * 2]; t2 += sred[(w * BN + tid) * 2 + 1]; }
+            t2 *= a.rinv[0][n0 + tid];
+            if (a.red_mode == 1) {      // four accumulator rows [4][2N]: a quarter of the row blocks adds to any one address
+                float* row = a.rws[0] + (int64_t)((m0 / BM) & 3) * 2 * a.N + n0 + tid;
+                __hip_atomic_fetch_add(row, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(row + a.N, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {                    // deterministic mode: one part per row block, summed in a fixed order by bn_bwd_reduce_final
+                float* w = a.rws[0] + (int64_t)(m0 / BM) * 2 * a.N + n0 + tid;
+                w[0] = t1;
+                w[a.N] = t2;
+            }
+        }
     }
     if constexpr (RED)
     for (int q = 0; q < a.nred; ++q) {
@@ -1022,8 +1189,8 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
     // EPI 6: the epilogue's mask bytes, loaded now (in FRONT of the DMA issues: vector-memory operations retire in order, so the
     // loop's counted waits stay exact) and consumed after the loop
     unsigned pmask[TM][4];
-    if constexpr (EPI == 6) {
-        if (grp == 0) nt_prefetch_mask<T, BM, BN, WMW>(a, m0, n0, pmask);
+    if constexpr (EPI == 6 || EPI == 7) {
+        if (grp == 0) nt_prefetch_mask<T, BM, BN, WMW, EPI == 6>(a, m0, n0, pmask);
     }
     // CAPMI_NT_ABL (tools/nt_ablate.hip only, 0 in the library): 1 = no MFMAs, 2 = no LDS reads either, 4 = no DMA
 #pragma unroll
@@ -1082,8 +1249,8 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
                 for (int j = 0; j < TN; ++j) xch[((grp - 1) * TM * TN + i * TN + j) * 256 + tid] = acc[i][j];
         }
         __syncthreads();
-        if (grp > 0) {                  // keep the barrier count of the epilogue's statistics path (two), then leave
-            if (a.stats) { lds_barrier(); lds_barrier(); }
+        if (grp > 0) {                  // keep the barrier count of the epilogue's statistics / batch-norm-sums path (two), then leave
+            if (a.stats || EPI == 7 || EPI == 8) { lds_barrier(); lds_barrier(); }
             return;
         }
 #pragma unroll
@@ -1093,7 +1260,7 @@ __device__ __forceinline__ void nt_glds_body(const IGemmArgs& a, int block, int 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] += xch[(g * TM * TN + i * TN + j) * 256 + tid];
     }
-    nt_epilogue<T, BM, BN, WMW, RED, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem), (int64_t)split * a.M * a.ldy, EPI == 6 ? pmask : nullptr);
+    nt_epilogue<T, BM, BN, WMW, RED, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem), (int64_t)split * a.M * a.ldy, (EPI == 6 || EPI == 7) ? pmask : nullptr);
 }
 
 template <int BM, int BN, int NST, bool RED = false, int LIN = 0, int EPI = 0>
@@ -1240,7 +1407,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
         __syncthreads();
     }
     unsigned pmask[TM][4];                                      // EPI 6: the epilogue's mask bytes, in front of the DMA issues (see nt_glds_body)
-    if constexpr (EPI == 6) nt_prefetch_mask<T, BM, BN, WMW>(a, m0, n0, pmask);
+    if constexpr (EPI == 6 || EPI == 7) nt_prefetch_mask<T, BM, BN, WMW, false>(a, m0, n0, pmask);      // (the halo kernel never scatters)
     // prologue: halo of chunk 0, filter tiles of steps 0 and 1 (taps 0 and 1 of chunk 0)
     issue_A(0, 0, true);
     issue_B(0, 0, true);
@@ -1334,7 +1501,7 @@ __global__ __launch_bounds__(256, BM == 64 ? 3 : 2) void igemm_nt_halo3_kernel(I
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // retire the (zero-page) tail issues before LDS reuse
     __syncthreads();
-    nt_epilogue<T, BM, BN, WMW, false, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem), 0, EPI == 6 ? pmask : nullptr);
+    nt_epilogue<T, BM, BN, WMW, false, true, EPI>(a, acc, m0, n0, reinterpret_cast<float*>(smem), 0, (EPI == 6 || EPI == 7) ? pmask : nullptr);
 }
 
 // Several independent problems (the parity classes of a strided data gradient) in ONE launch: the
@@ -1959,6 +2126,7 @@ extern "C" int capmi_lstm_seq_supported(int B, int H, int T, int dtype) {
     return 0;
 }
 static int seq_sync_reset(void* sync, hipStream_t st, const char* who) {
+    if (t_probe) return 0;
     hipError_t e = hipMemsetAsync(sync, 0, 8, st);          // arrival counter + this launch's gave-up flag; word 2 (sticky) stays
     if (e != hipSuccess) {
         capmi_set_error("%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
@@ -1990,7 +2158,7 @@ extern "C" int capmi_lstm_seq_fwd(void* hbuf, const void* wh, int ldw, void* gat
     hipStream_t st = (hipStream_t)stream;
     if (seq_sync_reset(sync, st, "capmi_lstm_seq_fwd")) return 1;
     const int fences = seq_fences();
-#define CAPMI_SEQ_FWD(TT, KS_) hipLaunchKernelGGL((lstm_seq_fwd_kernel<TT, KS_>), dim3(H / 8), dim3(256), 0, st, (TT*)hbuf, (const TT*)wh, ldw, (TT*)gates, (TT*)cbuf, B, H, T, (unsigned*)sync, fences)
+#define CAPMI_SEQ_FWD(TT, KS_) CAPMI_KLAUNCH((lstm_seq_fwd_kernel<TT, KS_>), dim3(H / 8), dim3(256), 0, st, (TT*)hbuf, (const TT*)wh, ldw, (TT*)gates, (TT*)cbuf, B, H, T, (unsigned*)sync, fences)
     if (dtype == CAPMI_BF16) {
         if (H == 256) CAPMI_SEQ_FWD(bf16, 2);
         else if (H == 384) CAPMI_SEQ_FWD(bf16, 3);
@@ -2015,7 +2183,7 @@ extern "C" int capmi_lstm_seq_bwd(const void* gates, const void* cbuf, const voi
     if (seq_sync_reset(sync, st, "capmi_lstm_seq_bwd")) return 1;
     const int fences = seq_fences();
     const dim3 grid(H / 32, (B + 15) / 16);
-#define CAPMI_SEQ_BWD(TT, KS_, NW_) hipLaunchKernelGGL((lstm_seq_bwd_kernel<TT, KS_, NW_>), grid, dim3(64 * NW_), 0, st, (const TT*)gates, (const TT*)cbuf, (const TT*)whT, ldwT, (const TT*)dhbuf, (TT*)dcbuf, (TT*)dgates, dc_outside, B, H, T, (unsigned*)sync, fences)
+#define CAPMI_SEQ_BWD(TT, KS_, NW_) CAPMI_KLAUNCH((lstm_seq_bwd_kernel<TT, KS_, NW_>), grid, dim3(64 * NW_), 0, st, (const TT*)gates, (const TT*)cbuf, (const TT*)whT, ldwT, (const TT*)dhbuf, (TT*)dcbuf, (TT*)dgates, dc_outside, B, H, T, (unsigned*)sync, fences)
     if (dtype == CAPMI_BF16) {
         if (H == 256) CAPMI_SEQ_BWD(bf16, 8, 4);
         else if (H == 384) CAPMI_SEQ_BWD(bf16, 12, 4);
@@ -2040,10 +2208,10 @@ extern "C" int capmi_lstm_step_fwd(const void* h_prev, const void* wh, int ldw, 
     const int vec = dtype == CAPMI_F32 ? 4 : 8;
     CAPMI_CHECK(ldw % vec == 0, "capmi_lstm_step_fwd: ldw=%d must be a multiple of %d", ldw, vec);
     if (dtype == CAPMI_BF16)
-        hipLaunchKernelGGL(lstm_step_fwd_kernel<bf16>, dim3(H / 8), dim3(256), 0, (hipStream_t)stream, (const bf16*)h_prev, (const bf16*)wh, ldw,
+        CAPMI_KLAUNCH(lstm_step_fwd_kernel<bf16>, dim3(H / 8), dim3(256), 0, (hipStream_t)stream, (const bf16*)h_prev, (const bf16*)wh, ldw,
                            (bf16*)gates, (const bf16*)c_prev, (bf16*)h, (bf16*)c, B, H);
     else
-        hipLaunchKernelGGL(lstm_step_fwd_kernel<float>, dim3(H / 8), dim3(256), 0, (hipStream_t)stream, (const float*)h_prev, (const float*)wh, ldw,
+        CAPMI_KLAUNCH(lstm_step_fwd_kernel<float>, dim3(H / 8), dim3(256), 0, (hipStream_t)stream, (const float*)h_prev, (const float*)wh, ldw,
                            (float*)gates, (const float*)c_prev, (float*)h, (float*)c, B, H);
     CAPMI_LAUNCH_CHECK("capmi_lstm_step_fwd");
     return 0;
@@ -2056,11 +2224,11 @@ extern "C" int capmi_lstm_step_bwd(const void* dgates_t, const void* whT, int ld
     const int vec = dtype == CAPMI_F32 ? 4 : 8;
     CAPMI_CHECK(ldwT % vec == 0, "capmi_lstm_step_bwd: ldwT=%d must be a multiple of %d", ldwT, vec);
     if (dtype == CAPMI_BF16)
-        hipLaunchKernelGGL(lstm_step_bwd_kernel<bf16>, dim3(H / 32), dim3(256), 0, (hipStream_t)stream, (const bf16*)dgates_t, (const bf16*)whT, ldwT,
+        CAPMI_KLAUNCH(lstm_step_bwd_kernel<bf16>, dim3(H / 32), dim3(256), 0, (hipStream_t)stream, (const bf16*)dgates_t, (const bf16*)whT, ldwT,
                            (const bf16*)dh_in, (const bf16*)gates_prev, (const bf16*)c_prev, (const bf16*)c, (const bf16*)dc_in, (bf16*)dgates_prev,
                            (bf16*)dc_prev, dc_prev_accumulate, B, H);
     else
-        hipLaunchKernelGGL(lstm_step_bwd_kernel<float>, dim3(H / 32), dim3(256), 0, (hipStream_t)stream, (const float*)dgates_t, (const float*)whT, ldwT,
+        CAPMI_KLAUNCH(lstm_step_bwd_kernel<float>, dim3(H / 32), dim3(256), 0, (hipStream_t)stream, (const float*)dgates_t, (const float*)whT, ldwT,
                            (const float*)dh_in, (const float*)gates_prev, (const float*)c_prev, (const float*)c, (const float*)dc_in, (float*)dgates_prev,
                            (float*)dc_prev, dc_prev_accumulate, B, H);
     CAPMI_LAUNCH_CHECK("capmi_lstm_step_bwd");
@@ -2111,8 +2279,8 @@ static int launch_nt(const IGemmArgs& a, hipStream_t st) {
     int64_t tiles = (int64_t)cdiv(a.M, BM) * cdiv(a.N, BN);
     if (tiles <= 0) return 0;
     CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
-    if (a.nred) hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WMW, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WMW>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    if (a.nred) CAPMI_KLAUNCH((igemm_nt_kernel<T, BM, BN, WMW, true>), dim3((unsigned)tiles), dim3(256), 0, st, a);
+    else CAPMI_KLAUNCH((igemm_nt_kernel<T, BM, BN, WMW>), dim3((unsigned)tiles), dim3(256), 0, st, a);
     CAPMI_LAUNCH_CHECK("capmi_igemm_nt");
     return 0;
 }
@@ -2151,6 +2319,8 @@ static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const
                     "capmi_igemm_nt: CAPMI_DACT_BITMASK is for bf16 convolution data gradients (relu / relu6; N, ldy, ld_saved, ld_addend multiples of 8; no bias / activation / statistics / f32 output)");
     }
     a.nred = nred;
+    a.red_mode = 0;
+    a.stat_sums = 0;
     for (int q = 0; q < 2; ++q) {
         a.rx[q] = q < nred ? red[q].x : nullptr; a.rmean[q] = q < nred ? red[q].mean : nullptr;
         a.rinv[q] = q < nred ? red[q].invstd : nullptr; a.rws[q] = q < nred ? red[q].ws : nullptr;
@@ -2170,36 +2340,36 @@ static int launch_glds_epi(const IGemmArgs& a, const capmi_conv_geom* g, bool li
     CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
     const dim3 grid((unsigned)tiles);
     if constexpr (BM == 128) {
-        if (!a.nred && tiles <= 256 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64))) {
-            if (lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2, EPI>), grid, dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2, EPI>), grid, dim3(512), 0, st, a);
+        if ((!a.nred || EPI == 7) && tiles <= 256 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64))) {
+            if (lin) CAPMI_KLAUNCH((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2, EPI>), grid, dim3(512), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2, EPI>), grid, dim3(512), 0, st, a);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds 128, k-groups)");
             return 0;
         }
     }
     if constexpr (BM == 64) {
         // deep K on an under-filled grid: 2 or 4 k-groups per workgroup (more waves, same tile)
-        const bool k2 = !a.nred && tiles < 512 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64));
+        const bool k2 = (!a.nred || EPI == 7) && tiles < 512 && a.K >= 1024 && (lin || (conv1 && g->Cin >= 64));
         const bool k4 = k2 && tiles <= 256 && a.K >= 2048 && (lin || g->Cin >= 128);
         if (k2) {
-            if (k4 && lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 4, EPI>), grid, dim3(1024), 0, st, a);
-            else if (k4) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 4, EPI>), grid, dim3(1024), 0, st, a);
-            else if (lin) hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2, EPI>), grid, dim3(512), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2, EPI>), grid, dim3(512), 0, st, a);
+            if (k4 && lin) CAPMI_KLAUNCH((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 4, EPI>), grid, dim3(1024), 0, st, a);
+            else if (k4) CAPMI_KLAUNCH((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 4, EPI>), grid, dim3(1024), 0, st, a);
+            else if (lin) CAPMI_KLAUNCH((igemm_nt_glds_kg_kernel<BM, BN, 3, 1, 2, EPI>), grid, dim3(512), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_glds_kg_kernel<BM, BN, 3, 2, 2, EPI>), grid, dim3(512), 0, st, a);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds, k-groups)");
             return 0;
         }
     }
     if constexpr (EPI == 0 || EPI == 4) {       // (the fused batch-norm backward sums ride on data gradients only)
         if (a.nred) {
-            hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, true, 0, EPI>), grid, dim3(256), 0, st, a);
+            CAPMI_KLAUNCH((igemm_nt_glds_kernel<BM, BN, 3, true, 0, EPI>), grid, dim3(256), 0, st, a);
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
             return 0;
         }
     }
-    if (lin) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 1, EPI>), grid, dim3(256), 0, st, a);
-    else if (conv1) hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 2, EPI>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((igemm_nt_glds_kernel<BM, BN, 3, false, 0, EPI>), grid, dim3(256), 0, st, a);
+    if (lin) CAPMI_KLAUNCH((igemm_nt_glds_kernel<BM, BN, 3, false, 1, EPI>), grid, dim3(256), 0, st, a);
+    else if (conv1) CAPMI_KLAUNCH((igemm_nt_glds_kernel<BM, BN, 3, false, 2, EPI>), grid, dim3(256), 0, st, a);
+    else CAPMI_KLAUNCH((igemm_nt_glds_kernel<BM, BN, 3, false, 0, EPI>), grid, dim3(256), 0, st, a);
     CAPMI_LAUNCH_CHECK("capmi_igemm_nt(glds)");
     return 0;
 }
@@ -2211,6 +2381,8 @@ static bool nt_conv_class(const IGemmArgs& a) {
 }
 // the data-gradient form with its mask as bits (the flag forces the class: no other epilogue reads bits)
 static bool nt_bits_class(const IGemmArgs& a) { return (a.dact & CAPMI_DACT_BITMASK) != 0; }
+// ... and with the batch-norm backward sums of the completed tensor's layer in the same epilogue (capmi_igemm_nt_bnsum)
+static bool nt_bnsum_class(const IGemmArgs& a) { return nt_bits_class(a) && a.red_mode != 0; }
 // conv class: 1 = the forward form (nothing but stores and statistics), 4 = the data-gradient form (no statistics)
 static bool nt_conv_fwd(const IGemmArgs& a) { return !a.addend && !a.dact && a.g.os <= 1 && !a.nred; }
 // 2 = a fully connected layer of the decoder / its data gradient (bias, addend; tanh or nothing on either side)
@@ -2229,7 +2401,9 @@ static bool nt_f32_class(const IGemmArgs& a) {
 }
 template <int BM, int BN>
 static int launch_glds(const IGemmArgs& a, const capmi_conv_geom* g, bool lin, bool conv1, hipStream_t st) {
+    if (nt_bnsum_class(a)) return launch_glds_epi<BM, BN, 7>(a, g, lin, conv1, st);
     if (nt_bits_class(a)) return launch_glds_epi<BM, BN, 6>(a, g, lin, conv1, st);
+    if (nt_conv_class(a) && nt_conv_fwd(a) && a.stat_sums) return launch_glds_epi<BM, BN, 8>(a, g, lin, conv1, st);
     if (nt_conv_class(a)) return nt_conv_fwd(a) ? launch_glds_epi<BM, BN, 1>(a, g, lin, conv1, st) : launch_glds_epi<BM, BN, 4>(a, g, lin, conv1, st);
     if (nt_fc_class(a)) return launch_glds_epi<BM, BN, 2>(a, g, lin, conv1, st);
     if (nt_inf_class(a)) return launch_glds_epi<BM, BN, 3>(a, g, lin, conv1, st);
@@ -2255,7 +2429,7 @@ static bool nt_halo3_ok(const IGemmArgs& a, const capmi_conv_geom* g, int nred) 
     // experiment knob: grids of at most this many 128 x 128 tiles take the k-group LDS-DMA kernel instead (8 waves per workgroup)
     static const int min_tiles = getenv("CAPMI_HALO3_MINTILES") ? atoi(getenv("CAPMI_HALO3_MINTILES")) : 0;
     if (min_tiles > 0 && (int64_t)cdiv(a.M, 128) * cdiv(a.N, 128) <= min_tiles) return false;
-    return !nred && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->up == 1 && g->pad == 1 && g->Hi == g->Ho && g->Wi == g->Wo &&
+    return (!nred || a.red_mode != 0) && g->kh == 3 && g->kw == 3 && g->sd == 1 && g->up == 1 && g->pad == 1 && g->Hi == g->Ho && g->Wi == g->Wo &&
            g->os <= 1 && g->Wi <= 56 && g->Wi * g->Hi > 64 && g->Cin % 32 == 0 && a.K == 9 * g->Cin && a.N >= 32;       // (7 x 7: the k-group kernel is faster)
 }
 
@@ -2275,8 +2449,8 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
     if (nt_uses_skinny(g, a.M, a.K, stats != nullptr, dtype)) {
         CAPMI_CHECK(nred == 0, "capmi_igemm_nt_bnred: not available for M <= 64 plain products (see capmi_igemm_nt_bnred_part_rows)");
         // decoder recurrence and other M <= 64 products: skinny kernel (64x32 tiles, K split over waves)
-        if (dtype == CAPMI_BF16) hipLaunchKernelGGL(igemm_nt_skinny_kernel<bf16>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(igemm_nt_skinny_kernel<float>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);
+        if (dtype == CAPMI_BF16) CAPMI_KLAUNCH(igemm_nt_skinny_kernel<bf16>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);
+        else CAPMI_KLAUNCH(igemm_nt_skinny_kernel<float>, dim3(cdiv(N, 32)), dim3(256), 0, st, a);
         CAPMI_LAUNCH_CHECK("capmi_igemm_nt(skinny)");
         return 0;
     }
@@ -2297,16 +2471,16 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
         CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt_bnact: grid too large");
         const dim3 grid((unsigned)tiles);
         if (kind == 1) {
-            if (bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, true, 1>), grid, dim3(256), 0, st, a);
-            else if (bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, true, 1>), grid, dim3(256), 0, st, a);
-            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, true, 1>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, true, 1>), grid, dim3(256), 0, st, a);
+            if (bm == 128 && bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 128, true, 1>), grid, dim3(256), 0, st, a);
+            else if (bm == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 64, true, 1>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 128, true, 1>), grid, dim3(256), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 64, true, 1>), grid, dim3(256), 0, st, a);
         } else {
 #define CAPMI_INBN_LAUNCH(BM_, BN_)                                                                                              \
             do {                                                                                                                 \
-                if (a.K <= 128) hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<BM_, BN_, 128>), grid, dim3(256), 0, st, a);       \
-                else if (a.K <= 256) hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<BM_, BN_, 256>), grid, dim3(256), 0, st, a);  \
-                else hipLaunchKernelGGL((igemm_nt_glds_inbn_kernel<BM_, BN_, INBN_KMAX>), grid, dim3(256), 0, st, a);            \
+                if (a.K <= 128) CAPMI_KLAUNCH((igemm_nt_glds_inbn_kernel<BM_, BN_, 128>), grid, dim3(256), 0, st, a);       \
+                else if (a.K <= 256) CAPMI_KLAUNCH((igemm_nt_glds_inbn_kernel<BM_, BN_, 256>), grid, dim3(256), 0, st, a);  \
+                else CAPMI_KLAUNCH((igemm_nt_glds_inbn_kernel<BM_, BN_, INBN_KMAX>), grid, dim3(256), 0, st, a);            \
             } while (0)
             if (bm == 128) CAPMI_INBN_LAUNCH(128, 128);
             else if (bn == 128) CAPMI_INBN_LAUNCH(64, 128);
@@ -2322,31 +2496,41 @@ static int nt_dispatch(const IGemmArgs& a, const capmi_conv_geom* g, int N, floa
         const int64_t tiles = (int64_t)cdiv(a.M, c.bm) * cdiv(N, bn);
         CAPMI_CHECK(tiles < (1ll << 31), "capmi_igemm_nt: grid too large");
         const dim3 grid((unsigned)tiles);
-        if (nt_bits_class(a)) {
-            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 6>), grid, dim3(256), 0, st, a);
-            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 6>), grid, dim3(256), 0, st, a);
-            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 6>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 6>), grid, dim3(256), 0, st, a);
+        if (nt_bnsum_class(a)) {
+            if (c.bm == 128 && bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 128, false, 7>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 64, false, 7>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 128, false, 7>), grid, dim3(256), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 64, false, 7>), grid, dim3(256), 0, st, a);
+        } else if (nt_bits_class(a)) {
+            if (c.bm == 128 && bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 128, false, 6>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 64, false, 6>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 128, false, 6>), grid, dim3(256), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 64, false, 6>), grid, dim3(256), 0, st, a);
+        } else if (nt_conv_class(a) && nt_conv_fwd(a) && a.stat_sums) {
+            if (c.bm == 128 && bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 128, false, 8>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 64, false, 8>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 128, false, 8>), grid, dim3(256), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 64, false, 8>), grid, dim3(256), 0, st, a);
         } else if (nt_conv_class(a) && nt_conv_fwd(a)) {
-            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 1>), grid, dim3(256), 0, st, a);
-            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 1>), grid, dim3(256), 0, st, a);
-            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 1>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 1>), grid, dim3(256), 0, st, a);
+            if (c.bm == 128 && bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 128, false, 1>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 64, false, 1>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 128, false, 1>), grid, dim3(256), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 64, false, 1>), grid, dim3(256), 0, st, a);
         } else if (nt_conv_class(a) && !a.stats) {
-            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 4>), grid, dim3(256), 0, st, a);
-            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 4>), grid, dim3(256), 0, st, a);
-            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 4>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 4>), grid, dim3(256), 0, st, a);
+            if (c.bm == 128 && bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 128, false, 4>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 64, false, 4>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 128, false, 4>), grid, dim3(256), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 64, false, 4>), grid, dim3(256), 0, st, a);
         } else if (nt_inf_class(a)) {
-            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128, false, 3>), grid, dim3(256), 0, st, a);
-            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64, false, 3>), grid, dim3(256), 0, st, a);
-            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128, false, 3>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64, false, 3>), grid, dim3(256), 0, st, a);
+            if (c.bm == 128 && bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 128, false, 3>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 64, false, 3>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 128, false, 3>), grid, dim3(256), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 64, false, 3>), grid, dim3(256), 0, st, a);
         } else {
-            if (c.bm == 128 && bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 128>), grid, dim3(256), 0, st, a);
-            else if (c.bm == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<128, 64>), grid, dim3(256), 0, st, a);
-            else if (bn == 128) hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 128>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((igemm_nt_halo3_kernel<64, 64>), grid, dim3(256), 0, st, a);
+            if (c.bm == 128 && bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 128>), grid, dim3(256), 0, st, a);
+            else if (c.bm == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<128, 64>), grid, dim3(256), 0, st, a);
+            else if (bn == 128) CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 128>), grid, dim3(256), 0, st, a);
+            else CAPMI_KLAUNCH((igemm_nt_halo3_kernel<64, 64>), grid, dim3(256), 0, st, a);
         }
         CAPMI_LAUNCH_CHECK("capmi_igemm_nt(halo 3x3)");
         return 0;
@@ -2449,7 +2633,7 @@ extern "C" int capmi_igemm_nt_bnfin(const void* x, const void* w, void* y, const
         if (!fused) a.fin_cnt = nullptr;
     }
     if (nt_dispatch(a, g, N, stats, 0, dtype, (hipStream_t)stream)) return 1;
-    if (fused) return 0;
+    if (fused || t_probe) return 0;
     return capmi_bn_finalize(stats, part_rows, a.M, N, scale, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, stream);
 }
 
@@ -2501,9 +2685,9 @@ extern "C" int capmi_igemm_nt_splitk(const void* x, const void* w, void* y, int 
     a.kper = kper;
     const int64_t tiles = (int64_t)cdiv(M, 128) * cdiv(N, 128);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL((igemm_nt_glds_kernel<128, 128, 3, false, 1>), dim3((unsigned)(tiles * S)), dim3(256), 0, st, a);
+    CAPMI_KLAUNCH((igemm_nt_glds_kernel<128, 128, 3, false, 1>), dim3((unsigned)(tiles * S)), dim3(256), 0, st, a);
     const int64_t MN = (int64_t)M * N;
-    hipLaunchKernelGGL(nt_splitk_reduce_kernel<bf16>, dim3(ew_grid(MN / 4)), dim3(256), 0, st, ws, S, MN, N, ldy, (bf16*)y);
+    CAPMI_KLAUNCH(nt_splitk_reduce_kernel<bf16>, dim3(ew_grid(MN / 4)), dim3(256), 0, st, ws, S, MN, N, ldy, (bf16*)y);
     CAPMI_LAUNCH_CHECK("capmi_igemm_nt_splitk");
     return 0;
 }
@@ -2566,6 +2750,82 @@ extern "C" int capmi_igemm_nt_bnred(const void* x, const void* w, void* y, const
     return igemm_nt_impl(x, w, y, g, N, ldw, ldy, nullptr, addend, ld_addend, ysaved, ld_saved, nullptr, 0, dact, 0, nred, red, dtype, stream);
 }
 
+/* 1 when capmi_igemm_nt_stat has a kernel with the sums epilogue (EPI 8) for this convolution: the bf16 LDS-DMA tiles and the
+ * halo-staged 3x3 kernel (dense shapes: N a multiple of 8, >= 32 columns).  0: launch capmi_igemm_nt with a parts workspace +
+ * capmi_bn_finalize + capmi_bn_apply. */
+extern "C" int capmi_igemm_nt_stat_supported(const capmi_conv_geom* g, int N, int dtype) {
+    if (!g || dtype != CAPMI_BF16 || N % 8 != 0 || N < 32 || g->os > 1) return 0;
+    const int M = g->B * g->Ho * g->Wo, K = g->kh * g->kw * g->Cin;
+    if (nt_uses_skinny(g, M, K, true, dtype)) return 0;
+    const NtCfg c = nt_cfg(M, N, K, dtype);
+    IGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.N = N; a.K = K; a.stats = reinterpret_cast<float*>(1);
+    if (nt_halo3_ok(a, g, 0)) return 1;
+    return (c.wmw == 5 || c.wmw == 6 || c.bn == 128) ? 1 : 0;
+}
+/* A training convolution with its batch statistics (IC/model/MobileNetV2.py:99-117: conv2d -> batch_norm, train mode) as
+ * capmi_bn_stat_apply consumes them.  Default (bf16): per-column sum v and sum v^2 of the f32 accumulators ADDED (f32 atomics)
+ * to stat_rows[4][2N], which the caller zeroes once per step.  Deterministic mode (capmi.h), or a shape without the sums
+ * epilogue when `parts` is given: the exact (mean, M2) parts of capmi_igemm_nt into `parts` instead -- capmi_bn_stat_apply
+ * makes the same choice from the same switch. */
+extern "C" int capmi_igemm_nt_stat(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                                   float* parts, float* stat_rows, int dtype, void* stream) {
+    CAPMI_CHECK(parts && stat_rows, "capmi_igemm_nt_stat: null statistics buffer");
+    CAPMI_CHECK(capmi_igemm_nt_stat_supported(g, N, dtype), "capmi_igemm_nt_stat: no kernel with the sums epilogue for this shape (capmi_igemm_nt_stat_supported)");
+    IGemmArgs a;
+    if (nt_prepare(a, x, w, y, g, N, ldw, ldy, nullptr, nullptr, 0, nullptr, 0, parts, 0, 0, 0, 0, nullptr, dtype)) return 1;
+    if (!capmi_deterministic()) {
+        a.stats = stat_rows;
+        a.stat_sums = 1;
+    }
+    return nt_dispatch(a, g, N, a.stats, 0, dtype, (hipStream_t)stream);
+}
+
+/* The kernel family that carries the batch-norm backward sums in its epilogue (EPI 7): the LDS-DMA tiles (any addressing mode,
+ * k-groups included) and the halo-staged 3x3 kernel; not the register-staged kernel (ragged / narrow shapes), not the skinny
+ * kernel, not grouped launches (strided data gradients).  Returns the row-block height of the per-tile parts (deterministic
+ * mode: parts workspace of ceil(M / height) * 2N floats), 0 when the shape has no such kernel. */
+extern "C" int capmi_igemm_nt_bnsum_part_rows(const capmi_conv_geom* g, int N, int dtype) {
+    if (!g || dtype != CAPMI_BF16 || N % 8 != 0 || N < 32 || g->os > 1) return 0;
+    const int M = g->B * g->Ho * g->Wo, K = g->kh * g->kw * g->Cin;
+    if (nt_uses_skinny(g, M, K, false, dtype) || (g->Hi == 1 && g->Wi == 1)) return 0;
+    const NtCfg c = nt_cfg(M, N, K, dtype);
+    IGemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = M; a.N = N; a.K = K; a.red_mode = 1;
+    if (nt_halo3_ok(a, g, 1)) return c.bm;
+    const bool glds = c.wmw == 5 || c.wmw == 6 || c.bn == 128;
+    return glds ? c.bm : 0;
+}
+/* capmi_igemm_nt (a convolution's data gradient with its ReLU mask as bits: dact carries CAPMI_DACT_BITMASK) that ALSO takes the
+ * batch-norm backward sums of the layer whose output gradient it completes -- `raw` is that layer's conv output [M][N] (same
+ * rows as y), mean / invstd its saved statistics: sum_m dz and sum_m dz * (raw - mean) * invstd per channel, dz = the stored
+ * (masked, bf16) gradient.  Default: added to acc_rows[4][2N] (f32 atomics; the rows capmi_bn_bwd_apply_spread consumes,
+ * zeroed by the caller once per step) -- capmi_bn_bwd_reduce_spread of that layer is not launched at all.  Deterministic mode
+ * (capmi.h): per-tile parts into parts_ws + a fixed-order sum into red ([d offset | d scale]), what capmi_bn_bwd_reduce leaves.
+ * IC/model/MobileNetV2.py:112-119 backward (batch_norm_grad's reductions) inside conv2d_grad of the consumer. */
+extern "C" int capmi_igemm_nt_bnsum(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
+                                    const void* addend, int ld_addend, const void* maskbits, int ld_saved, int dact,
+                                    const void* raw, const float* mean, const float* invstd, float* acc_rows, float* parts_ws,
+                                    float* red, int dtype, void* stream) {
+    CAPMI_CHECK(raw && mean && invstd && acc_rows, "capmi_igemm_nt_bnsum: null batch-norm operand");
+    CAPMI_CHECK((dact & CAPMI_DACT_BITMASK) && maskbits, "capmi_igemm_nt_bnsum: the ReLU mask must come as bits (CAPMI_DACT_BITMASK)");
+    CAPMI_CHECK(ldy == N, "capmi_igemm_nt_bnsum: output must be dense (ldy == N)");
+    const int part_rows = capmi_igemm_nt_bnsum_part_rows(g, N, dtype);
+    CAPMI_CHECK(part_rows > 0, "capmi_igemm_nt_bnsum: no kernel with the sums epilogue for this shape (capmi_igemm_nt_bnsum_part_rows)");
+    const bool det = capmi_deterministic() != 0;
+    CAPMI_CHECK(!det || (parts_ws && red), "capmi_igemm_nt_bnsum: deterministic mode needs the parts workspace and red");
+    IGemmArgs a;
+    if (nt_prepare(a, x, w, y, g, N, ldw, ldy, nullptr, addend, ld_addend, maskbits, ld_saved, nullptr, 0, dact, 0, 0, nullptr, dtype)) return 1;
+    a.nred = 1;
+    a.red_mode = det ? 2 : 1;
+    a.rx[0] = raw; a.rmean[0] = mean; a.rinv[0] = invstd; a.rws[0] = det ? parts_ws : acc_rows;
+    if (nt_dispatch(a, g, N, nullptr, 1, dtype, (hipStream_t)stream)) return 1;
+    if (det && !t_probe) return capmi_bn_bwd_reduce_final(parts_ws, cdiv(a.M, part_rows), N, red, stream);
+    return 0;
+}
+
 /* Independent NT products (disjoint outputs) issued together; see capmi.h. */
 extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count, int dtype, void* stream) {
     CAPMI_CHECK(calls && count >= 1, "capmi_igemm_nt_group: bad arguments");
@@ -2608,25 +2868,25 @@ extern "C" int capmi_igemm_nt_group(const capmi_igemm_nt_call* calls, int count,
             bool fc = !cc;
             for (int i = 0; i < n; ++i) fc = fc && nt_fc_class(grp.a[i]);
             if (fuse128 && allbits) {
-                if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
-                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                if (conv1) CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 128, 3, 2, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 128, 3, 0, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (fuse128 && cc) {
-                if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
-                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                if (conv1) CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 128, 3, 2, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 128, 3, 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (fuse128) {
-                if (conv1) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
-                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 128, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                if (conv1) CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 128, 3, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 128, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (allbits) {           // (the same tile as without the bits: the kernel choice must not depend on the mask's form)
-                if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
-                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                if (lin) CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 64, 3, 1, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 64, 3, 0, 6>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (fc && lin) {         // the decode step's grouped projections (bias, tanh)
-                hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 64, 3, 1, 2>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else if (cc) {
-                if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
-                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                if (lin) CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 64, 3, 1, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 64, 3, 0, 4>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             } else {
-                if (lin) hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
-                else hipLaunchKernelGGL((igemm_nt_glds_group_kernel<64, 64, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                if (lin) CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 64, 3, 1>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
+                else CAPMI_KLAUNCH((igemm_nt_glds_group_kernel<64, 64, 3, 0>), dim3((unsigned)blocks), dim3(256), 0, st, grp);
             }
             CAPMI_LAUNCH_CHECK("capmi_igemm_nt_group");
         } else {
@@ -3108,13 +3368,13 @@ static int launch_tn(WGradArgs& a, float* ws, long long ws_bytes, hipStream_t st
         // slower, in the step it is worth 0.10 ms (8.84 -> 8.74, A/B on one box); 32 KB (two 32-row stages) starves the kernel
         // itself (+0.2 ms).  CAPMI_TN_SMALL = 0 / 1 / 2 selects 64 / 32 / 48 KB (lesson 47).
         static const int small = getenv("CAPMI_TN_SMALL") ? atoi(getenv("CAPMI_TN_SMALL")) : 2;
-        if (small == 1) hipLaunchKernelGGL((igemm_tn_glds_kernel<0, 2, 1, false, 32>), dim3(tiles * splits), dim3(512), 0, st, a);
-        else if (small == 2) hipLaunchKernelGGL((igemm_tn_glds_kernel<0, 3, 1, false, 32>), dim3(tiles * splits), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL(igemm_tn_glds_kernel<0>, dim3(tiles * splits), dim3(512), 0, st, a);
+        if (small == 1) CAPMI_KLAUNCH((igemm_tn_glds_kernel<0, 2, 1, false, 32>), dim3(tiles * splits), dim3(512), 0, st, a);
+        else if (small == 2) CAPMI_KLAUNCH((igemm_tn_glds_kernel<0, 3, 1, false, 32>), dim3(tiles * splits), dim3(512), 0, st, a);
+        else CAPMI_KLAUNCH(igemm_tn_glds_kernel<0>, dim3(tiles * splits), dim3(512), 0, st, a);
     }
-    else hipLaunchKernelGGL((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles * splits), dim3(256), 0, st, a);
+    else CAPMI_KLAUNCH((igemm_tn_kernel<T, BNO, BKO>), dim3(tiles * splits), dim3(256), 0, st, a);
     if (use_slab)
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(a.Np / 32, a.Kp / 32), dim3(256), 0, st, ws, splits, a.Np, a.Kp, a.dw, a.N, a.K, a.lddw);
+        CAPMI_KLAUNCH(wgrad_reduce_kernel, dim3(a.Np / 32, a.Kp / 32), dim3(256), 0, st, ws, splits, a.Np, a.Kp, a.dw, a.N, a.K, a.lddw);
     CAPMI_LAUNCH_CHECK("capmi_igemm_tn_wgrad");
     return 0;
 }

@@ -59,6 +59,9 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_igemm_nt_bnact),
     CAPMI_ENTRY(capmi_igemm_nt_bnfin),
     CAPMI_ENTRY(capmi_igemm_nt_bnred),
+    CAPMI_ENTRY(capmi_igemm_nt_bnsum),
+    CAPMI_ENTRY(capmi_igemm_nt_stat),
+    CAPMI_ENTRY(capmi_bn_stat_apply),
     CAPMI_ENTRY(capmi_igemm_tn_wgrad),
     CAPMI_ENTRY(capmi_colsum),
     CAPMI_ENTRY(capmi_im2col_stem),

@@ -80,6 +80,24 @@ class GradBuckets:
         return len(self.ranges)
 
 
+def bucket_cut_points(store):
+    """Flat offsets at which everything below is final once the backward pass has got that far: the decoder's parameters first,
+    then the encoder's layers from last to first (params.ParamStore lays the flat buffer out in exactly that order; a layer's
+    group ends with its batch-norm scale).  The data-parallel step may only cut a bucket at one of these."""
+    import numpy as np
+    cuts = [store.decoder_size]
+    for name, e in store.entries.items():
+        if name.endswith('_bn_scale') and e.offset >= store.decoder_size:
+            cuts.append(e.offset + (int(np.prod(e.kshape)) + 7) // 8 * 8)
+    return [c for c in cuts if c <= store.trainable_size]
+
+
+def bucket_plan(store, bucket_bytes=32 << 20, elem_bytes=4):
+    """The gradient buckets of a model (GradBuckets over bucket_cut_points): what OverlappedTrainer exchanges per step,
+    whatever the device -- the plan depends on the parameter layout only."""
+    return GradBuckets(store.trainable_size, bucket_cut_points(store), bucket_bytes, elem_bytes)
+
+
 def allreduce_flat(flat, buckets, group=None, async_op=False):
     """Sum-all-reduce `flat` bucket by bucket.  Returns the work handles when async."""
     works = []
@@ -171,12 +189,13 @@ class OverlappedTrainer:
         self.eng = engine
         self.bucket_bytes = bucket_bytes
         self.active = engine.world > 1 or (engine.pg is not None and os.environ.get('CAPMI_FORCE_DP', '0') not in ('', '0'))
-        # Payload type of the gradient exchange.  'bf16' (default of a bf16 engine; SURVEY.md section 8(e) budgets the exchange
-        # in bf16: 73 MB at BASELINE cfg 2 instead of 146): the bucket's f32 gradients are cast into a bf16 staging buffer by
-        # the bucket's producer lane, the ring sums in bf16, Adam widens them again (capmi_adam_g16).  'f32' (default of an f32
-        # engine, CAPMI_BUCKET_DTYPE=f32 anywhere): the reference's precision, ParallelExecutor all-reduces f32 gradients.
-        from ._lib import BF16
-        self.bucket_dtype = bucket_dtype or os.environ.get('CAPMI_BUCKET_DTYPE') or ('bf16' if engine.code == BF16 else 'f32')
+        # Payload type of the gradient exchange.  'f32' (the default of every engine): the reference's precision -- ParallelExecutor
+        # all-reduces f32 gradients (train.py:121-124).  'bf16' (opt-in: bucket_dtype='bf16' / CAPMI_BUCKET_DTYPE=bf16; SURVEY.md
+        # section 8(e) budgets the exchange in bf16: 73 MB at BASELINE cfg 2 instead of 146): the bucket's f32 gradients are cast
+        # into a bf16 staging buffer by the bucket's producer lane, the ring sums in bf16 (every hop rounds), Adam widens them
+        # again (capmi_adam_g16).  It stays opt-in until a run on more than one GPU has shown loss parity with the f32 exchange:
+        # the one-rank and gloo tests cannot (round-3 advisor finding).
+        self.bucket_dtype = bucket_dtype or os.environ.get('CAPMI_BUCKET_DTYPE') or 'f32'
         if self.bucket_dtype not in ('f32', 'bf16'):
             raise ValueError('bucket_dtype must be f32 or bf16, got %r' % (self.bucket_dtype,))
         # CAPMI_COMM_PRIORITY=-1 puts the bucket stream (all-reduce + the bucket's optimizer) above the backward kernels;
@@ -226,6 +245,7 @@ class OverlappedTrainer:
         cuts = [(ci, off) for ci, off in cuts if off <= total]
         assert all(a[1] <= b[1] and a[0] <= b[0] for a, b in zip(cuts, cuts[1:])), 'gradient order != backward order'
         buckets = GradBuckets(total, [off for _, off in cuts], self.bucket_bytes)
+        assert buckets.ranges == bucket_plan(st, self.bucket_bytes).ranges, 'the backward plan marks and the parameter layout disagree on the cut points'
         index_of = {off: ci for ci, off in cuts}
         segs, start = [], 0
         for (b, e) in buckets:

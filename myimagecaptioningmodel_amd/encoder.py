@@ -157,6 +157,15 @@ class EncoderRunner:
         # finalizes when the library is built with -DCAPMI_FIN=1).  Measured slower than the dependent launch it removes (DESIGN.md
         # lesson 48): off by default.
         self.bnfin = os.environ.get('CAPMI_BNFIN', '0') != '0'
+        # batch-norm BACKWARD sums in the epilogue of the data gradient that completes the layer's output gradient
+        # (capmi_igemm_nt_bnsum, igemm.hip EPI 7): the layer's capmi_bn_bwd_reduce_spread launch -- two tensor reads on the
+        # dependency chain -- is gone wherever that data gradient is a dense launch with its mask as bits.  CAPMI_BNSUM=0: off.
+        self.bnsum = os.environ.get('CAPMI_BNSUM', '1') != '0'
+        # forward statistics as sums the convolution's epilogue adds into four accumulator rows per layer (capmi_igemm_nt_stat,
+        # igemm.hip EPI 8) + mean / invstd formed in the prologue of the apply launch (capmi_bn_stat_apply): the merge + finalize
+        # launch behind every convolution of the forward chain is gone.  bf16 only; deterministic mode switches both entry points
+        # back to the exact parts inside the library.  CAPMI_STAT_APPLY=0: conv -> capmi_bn_finalize -> capmi_bn_apply.
+        self.stat_apply = dtype_code == 1 and os.environ.get('CAPMI_STAT_APPLY', '1') != '0'
         # activation-derivative bit masks (capmi_bn_apply_mask): one bit per element of every ReLU / ReLU6 tensor, written next to the
         # activated tensor in the forward pass; the data-gradient epilogue that masks the tensor's gradient reads them instead of the
         # tensor, and reads them in FRONT of its main loop (igemm.hip EPI 6, nt_prefetch_mask: a byte per row and lane): a mask-only
@@ -169,7 +178,9 @@ class EncoderRunner:
                     fa = self.fused_add.get(op.dst)
                     out_id, act = (fa.dst, fa.act) if fa is not None else (op.dst, op.act)
                     h, w, c = self.shape[out_id]
-                    if act in ('relu', 'relu6') and c % 8 == 0 and c >= 32 and out_id != enc.out:
+                    # (layers whose finalize rides inside the apply launch -- capmi_bn_finalize_apply, CAPMI_BN_FA_MAXM -- write no bits:
+                    # their data gradients keep reading the saved output)
+                    if act in ('relu', 'relu6') and c % 8 == 0 and c >= 32 and out_id != enc.out and B * h * w > self.fa_max_rows:
                         self.maskbits[out_id] = z((B * h * w * c // 8,), torch.uint8)
         self.bn_acc, off = {}, 0
         for op in enc.ops:
@@ -177,6 +188,12 @@ class EncoderRunner:
                 self.bn_acc[op.dst] = off
                 off += 16 * self.shape[op.dst][2]
         self.bn_acc_all = z((max(off, 4),), torch.float32) if self.bn_spread else None
+        self.fwd_rows, off = {}, 0          # accumulator rows [4][2C] of the forward statistics (capmi_igemm_nt_stat), zeroed at the head of every forward plan
+        for op in enc.ops:
+            if isinstance(op, arch.ConvBN) and id(op) not in self.skipped:
+                self.fwd_rows[op.dst] = off
+                off += 8 * self.shape[op.dst][2]
+        self.fwd_rows_all = z((max(off, 4),), torch.float32) if self.stat_apply else None
         self.bwd_ws = z((ws,), torch.float32) if need_backward else None  # partial sums of bn_bwd_reduce (scratch)
         self.bwd_ws_side = z((ws,), torch.float32) if need_backward else None
         # partial sums written by data-gradient epilogues (capmi_igemm_nt_bnred): <= one part per 64 rows (+ class tails)
@@ -280,6 +297,9 @@ class EncoderRunner:
             self.coef_jobs = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(self.dev)
             plan.add('capmi_bn_inference_coef_batched', _p(self.coef_jobs), len(convs), int(table[:, 5].max()), BN_EPS)
         deferred = []               # bn_apply launches moved off the forward chain (operand-path batch norm)
+        use_sa = self.stat_apply and not is_test and not self.bnfin
+        if use_sa:
+            plan.add('capmi_fill_f32', _p(self.fwd_rows_all), 0.0, self.fwd_rows_all.numel())
         for op in self.enc.ops:
             if id(op) in self.skipped:
                 continue
@@ -313,11 +333,19 @@ class EncoderRunner:
                         side_out.add(op.dst)
                     continue
                 finalized = False
+                # statistics as accumulator rows + finalize inside the apply launch (capmi_igemm_nt_stat / capmi_bn_stat_apply)
+                sa_geom = (self._stem_geom(op) if op.src == 0 else self._conv_geom(op)) if op.groups == 1 else None
+                sa = (use_sa and op.groups == 1 and id(op) not in self.inbn and op.dst not in self.inbn_tensors and M > self.fa_max_rows
+                      and lib().capmi_igemm_nt_stat_supported(sa_geom, c, code) == 1)
+                sa_rows = self.fwd_rows_all.data_ptr() + 4 * self.fwd_rows[op.dst] if sa else None
                 if op.src == 0:        # stem: space-to-depth of the NCHW feed, then an ordinary stride-1 implicit GEMM
                     plan.add('capmi_s2d_stem', _p(image), _p(self.s2d), B, op.cin, self.S, self.S, op.pad, self.stem_hb, self.stem_wb,
                              self.stem_cs, code)
-                    plan.add('capmi_igemm_nt', _p(self.s2d), _p(w), _p(raw), self._stem_geom(op), c, self.kpad_of(op), c, None, None, 0, None, 0,
-                             None if is_test else _p(bn['stats']), 0, 0, 0, code)
+                    if sa:
+                        plan.add('capmi_igemm_nt_stat', _p(self.s2d), _p(w), _p(raw), sa_geom, c, self.kpad_of(op), c, _p(bn['stats']), sa_rows, code)
+                    else:
+                        plan.add('capmi_igemm_nt', _p(self.s2d), _p(w), _p(raw), self._stem_geom(op), c, self.kpad_of(op), c, None, None, 0, None, 0,
+                                 None if is_test else _p(bn['stats']), 0, 0, 0, code)
                 elif op.groups > 1:
                     hi, wi, _ = self.shape[op.src]
                     plan.add('capmi_dwconv3x3_fwd', _p(self.act[op.src]), _p(w), _p(raw), B, hi, wi, c, op.stride, ho, wo, code)
@@ -339,10 +367,12 @@ class EncoderRunner:
                                  _p(st.view(op.name + '_bn_scale')), _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']),
                                  BN_MOMENTUM, BN_EPS, _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, code, lane=ln)
                         finalized = True
+                    elif sa:
+                        plan.add('capmi_igemm_nt_stat', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, _p(bn['stats']), sa_rows, code, lane=ln)
                     else:
                         plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
                                  None if is_test else _p(bn['stats']), 0, 0, 0, code, lane=ln)
-                if not is_test:
+                if not is_test and not sa:
                     # small layers (stage 4 / 5 of a ResNet at batch 64): finalize inside the apply launch -- one dependent
                     # ~5 us kernel less on the forward chain; on big layers every one of thousands of apply workgroups would
                     # redo the merge (measured slower, capmi.h)
@@ -357,7 +387,11 @@ class EncoderRunner:
 
                 def apply(res, out, act, lane, out_id=None):
                     bits = self.maskbits.get(out_id) if (out_id is not None and not is_test) else None
-                    if bits is not None and not fused_here:
+                    if sa:
+                        plan.add('capmi_bn_stat_apply', _p(raw), _p(bn['stats']), bn['part_rows'], sa_rows, M, c, _p(st.view(op.name + '_bn_scale')), offset,
+                                 _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS, _p(bn['mean']),
+                                 _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, res, out, _p(bits), act, code, lane=lane)
+                    elif bits is not None and not fused_here:
                         plan.add('capmi_bn_apply_mask', _p(raw), _p(bn['mean']), _p(bn['a']), offset, res, out, _p(bits), M, c, act, code, lane=lane)
                     elif fused_here:
                         plan.add('capmi_bn_finalize_apply', _p(bn['stats']), bn['part_rows'], M, c, _p(st.view(op.name + '_bn_scale')), offset,
@@ -495,6 +529,7 @@ class EncoderRunner:
                 f = self.fused_add.get(o.dst)
                 conv_of_out[f.dst if f else o.dst] = o
         reduced = {}                    # id(ConvBN) -> (workspace, parts): BN backward sums already taken by a dgrad epilogue
+        summed = set()                  # id(ConvBN): sums already in the layer's accumulator rows (capmi_igemm_nt_bnsum)
         pool_fused = {}                 # tensor id -> the MaxPool whose backward its producer's batch-norm backward carries
 
         def consumers_of(t):
@@ -571,6 +606,11 @@ class EncoderRunner:
                              _p(bn['invstd']), _p(self.bwd_ws), _p(red), acc, _p(self.grad[out_id]), *pargs)
                     plan.add('capmi_bn_bwd_apply_pool', _p(self.grad[pool.dst]), _p(self.pool_idx[pool.dst]), _p(raw), _p(y), _p(bn['mean']),
                              _p(bn['invstd']), _p(st.view(op.name + '_bn_scale')), _p(red), acc, _p(self.grad[out_id]), _p(draw), *pargs)
+                elif id(op) in summed:
+                    # the data gradient that completed dy took the sums in its epilogue: accumulator rows (or, deterministic, red) are final
+                    assert act == NONE and not ln
+                    summed.discard(id(op))
+                    spread = self.bn_acc_all.data_ptr() + 4 * self.bn_acc[op.dst]
                 elif self.bn_spread:
                     spread = self.bn_acc_all.data_ptr() + 4 * self.bn_acc[op.dst]
                     plan.add('capmi_bn_bwd_reduce_spread', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
@@ -679,8 +719,19 @@ class EncoderRunner:
                             ws_busy[q] = id(X)
                     elif op.stride == 1:
                         gd, wkey, Kd = launches[0]
-                        plan.add('capmi_igemm_nt', _p(draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin,
-                                 None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code, lane=ln)
+                        X = conv_of_out.get(t)          # the layer whose output gradient this launch completes
+                        if (self.bnsum and self.bn_spread and not ln and mask and t in self.maskbits and X is not None and id(X) not in early
+                                and X.dst in self.bn_acc and not (self.pool_fuse and t in pool_fused)
+                                and lib().capmi_igemm_nt_bnsum_part_rows(gd, op.cin, code) > 0):
+                            bq = self.bn[X.dst]
+                            plan.add('capmi_igemm_nt_bnsum', _p(draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin, _p(addend), op.cin,
+                                     ysaved, op.cin, dact, _p(self.raw[X.dst]), _p(bq['mean']), _p(bq['invstd']),
+                                     self.bn_acc_all.data_ptr() + 4 * self.bn_acc[X.dst], _p(self.red_ws[0]),
+                                     _p(st.gview(X.name + '_bn_offset')), code)
+                            summed.add(id(X))
+                        else:
+                            plan.add('capmi_igemm_nt', _p(draw), _p(weights_bwd(wkey)), _p(dx), gd, op.cin, Kd, op.cin,
+                                     None, _p(addend), op.cin, ysaved, op.cin, None, 0, dact, 0, code, lane=ln)
                     else:
                         # strided conv: one dense GEMM per output-parity class over the compact grid,
                         # rows scattered to pixels (s*i+ph, s*j+pw) -- no MFMA on structural zeros; the

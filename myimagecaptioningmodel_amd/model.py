@@ -288,7 +288,9 @@ class CaptionEngine:
             raise ValueError('caption feed must be %s, got %s' % ((B, cfg['sentence_length']), tuple(cap.shape)))
         # Laned plans are launched eagerly (capmi_plan_run patches the slot); a plan replayed from a hipGraph has its pointers
         # frozen at capture and reads the staging tensor
-        eager = (not self.use_graph) or (prog['fwd'].has_lanes and self.overlap_lanes and os.environ.get('CAPMI_LANES', '1') != '0')
+        # (the plan that holds the image read: the encoder part when the decoder forward is replayed from its own hipGraph)
+        img_plan = prog['fwd_parts'][0] if self.graph_decoder_forward else prog['fwd']
+        eager = (not self.use_graph) or (img_plan.has_lanes and self.overlap_lanes and os.environ.get('CAPMI_LANES', '1') != '0')
         if eager and img.is_contiguous() and os.environ.get('CAPMI_FEED_COPY', '0') != '1':
             prog['image_slot'].value = img.data_ptr()       # the caller's own float32 device tensor (or the device copy just made of a host
             prog['image_ref'] = img                         # feed): read in place; kept alive until the next feed -- the caller must not rewrite it before the step ran

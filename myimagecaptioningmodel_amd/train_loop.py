@@ -33,6 +33,36 @@ def load_model(engine, conf, checkpoint_path, log_path, pretrained_encoder_path=
             ckpt.load_vars_existing(engine, pretrained_encoder_path)
 
 
+def dev_evaluation(engine, dev_batches, metric, log_path=None, index_word=None):
+    """The in-loop dev evaluation of train.py:151-169 as an `eval_score` callable for train(): per dev batch one greedy
+    decode through the in-training eval graph (`eval_exe.run(feed={'image': ...}, fetch_list=[caption])`, :163 -- batch
+    statistics, and the running statistics ARE updated by it: quirk Q3, the eval program shares the train program's
+    variables), the caller's `metric(pred_ids, real_captions) -> float` per batch in place of evaluate.calc_bleu (nltk, out
+    of scope: SURVEY.md section 2), the mean over the batches as the score (:165), and the count of distinct filtered
+    sentences (:166-167) in the log line.
+
+    dev_batches: callable epoch -> iterable of (images float32 [B,3,S,S], real captions) pairs (the `dev` reader of :152).
+    pred_ids handed to `metric` are the float32 id matrix [B, Ti] exactly as fetched (quirk Q2)."""
+    from . import decode
+    cfg = engine.cfg
+
+    def eval_score(epoch):
+        total, n = 0.0, 0
+        sentence_said = set()
+        for images, real_cap in dev_batches(epoch):
+            cp = engine.decode(images).detach().cpu().numpy()                # :163
+            total += float(metric(cp, real_cap))                             # :164
+            for p in cp.tolist():                                            # :165-166
+                sentence_said.add(decode.words2sentence(decode.ids_to_tokens(p, cfg['stop_idx'], cfg['padding_idx'], index_word)))
+            n += 1
+        score = total / max(1, n)                                            # :167
+        if log_path is not None:
+            log(log_path, 'Dev set: BLEU 分数: {:.7f} 语句数: {}'.format(score, len(sentence_said)))
+        eval_score.sentences = len(sentence_said)
+        return score
+    return eval_score
+
+
 def _rank_world(engine):
     pg = getattr(engine, 'pg', None)
     if pg is None:
@@ -73,6 +103,24 @@ def train(engine, batches_per_epoch, max_epoch, checkpoint_path, log_path, log_e
     if not lead:        # reads only: the train_encoder flip (if any) was recorded by rank 0 above
         load_model(engine, dict(conf, train_encoder=bool(engine.cfg['encoder_trainable'])), checkpoint_path, log_path, pretrained_encoder_path)
     step_fn = trainer.train_step if trainer is not None else engine.train_step
+
+    def all_ok(err):
+        """Data parallel: every rank learns whether ANY rank failed in this step (a sticky grid-barrier time-out, a NaN loss, a
+        reader or metric exception) before the next collective -- a rank that raised alone would leave the others waiting in
+        the next bucket all-reduce for ever.  One 4-byte all-reduce per step on the host-visible path; every rank then raises
+        (the failing one its own error), which also tears the process group down."""
+        if dist is None or world <= 1:
+            if err is not None:
+                raise err
+            return
+        import torch
+        flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float32,
+                            device=engine.device if dist.get_backend(engine.pg) == 'nccl' else 'cpu')
+        dist.all_reduce(flag, group=engine.pg)
+        if err is not None:
+            raise err
+        if float(flag.item()) > 0:
+            raise RuntimeError('capmi train loop: another rank failed in this step (rank %d stops with it)' % rank)
     for epoch in range(conf['epoch'], max_epoch + 1):
         conf['epoch'] = epoch                                   # written at the START of the epoch (train.py:134)
         if lead:
@@ -80,16 +128,26 @@ def train(engine, batches_per_epoch, max_epoch, checkpoint_path, log_path, log_e
             log(log_path, 'Epoch {}'.format(epoch))
         epoch_loss, step = 0.0, -1
         for step, data in enumerate(batches_per_epoch(epoch)):
-            loss, lr = step_fn(data['image'], data['caption'])
-            step_loss = loss.detach().cpu().numpy()
-            engine.check_sync()
-            if np.isnan(step_loss).any():                       # train.py:140-141
-                raise AssertionError('Epoch:{} Step:{} Loss为Nan'.format(epoch, step + 1))
+            err = None
+            try:
+                loss, lr = step_fn(data['image'], data['caption'])
+                step_loss = loss.detach().cpu().numpy()
+                engine.check_sync()
+                if np.isnan(step_loss).any():                       # train.py:140-141
+                    raise AssertionError('Epoch:{} Step:{} Loss为Nan'.format(epoch, step + 1))
+            except Exception as e:                                  # noqa: BLE001 -- re-raised by all_ok on every rank
+                err = e
+            all_ok(err)
             epoch_loss += float(step_loss[0])
             if lead and (step + 1) % log_every_n_step == 0:
                 log(log_path, ' ' * 4 + 'Step {} Mean loss: {:6f} Step loss: {:6f}, lr: {}'.format(
                     step + 1, epoch_loss / (step + 1), float(step_loss[0]), str(np.float32(lr))))
-        score = eval_score(epoch) if eval_score is not None else None                 # train.py:151-169 (dev BLEU)
+        err, score = None, None
+        try:
+            score = eval_score(epoch) if eval_score is not None else None             # train.py:151-169 (dev BLEU)
+        except Exception as e:                                      # noqa: BLE001
+            err = e
+        all_ok(err)
         if lead:
             log(log_path, 'Epoch loss: {:7f}'.format(epoch_loss / max(1, step + 1)))
             ckpt.save_persistables(engine, os.path.join(checkpoint_path, 'checkpoint'))   # train.py:172 -> :73

@@ -153,7 +153,7 @@ def _cfg2_worker(port, q):
     assert dist.get_backend(pg) == 'nccl'
     cfg = default_cfg(batch_size=32, sample_count=0, **bench.WORKLOAD)
     eng = CaptionEngine(cfg, device='cuda:0', use_graph=True, process_group=pg)
-    assert dp.OverlappedTrainer(eng).bucket_dtype == 'bf16'            # what bench.py --gpus N runs: a bf16 engine exchanges bf16 buckets
+    assert dp.OverlappedTrainer(eng).bucket_dtype == 'f32'             # what bench.py --gpus N runs: the reference's f32 exchange (bf16 buckets are opt-in)
     trainer = dp.OverlappedTrainer(eng, bucket_dtype='f32')             # default 32 MiB buckets; f32 payload: comparable bit for bit
     assert trainer.active
     assert trainer.native_comm is not None and trainer.native_comm.ok, getattr(trainer.native_comm, 'why', 'no native communicator')

@@ -293,6 +293,82 @@ def test_dgrad_with_fused_bn_backward_sums(dtype, B, C, H, W, Co, k, s, pad):
         assert np.abs(host(red) - want).max() <= 2e-3 * np.abs(want).max() + 1e-3, 'fused BN sums %d' % q
 
 
+@pytest.mark.parametrize('B,C,H,W,Co,k,addend', [
+    (4, 128, 56, 56, 64, 1, False),      # 98 x 1 tiles of 128 x 128 would under-fill: 64 x 128 tiles, K = 64
+    (16, 256, 56, 56, 64, 1, True),      # 128 x 128 LDS-DMA tiles (>= 384 tiles), addend (the shortcut gradient)
+    (8, 64, 28, 28, 256, 1, False),      # 64 x 64 tiles
+    (8, 128, 28, 28, 128, 3, False),     # halo-staged 3 x 3, 64 x 128 or 128 x 128
+    (16, 64, 56, 56, 64, 3, False),      # halo-staged 3 x 3, 64-column tiles
+    (8, 512, 14, 14, 2048, 1, True),     # deep K on a small grid: k-groups
+    (4, 512, 7, 7, 512, 3, False),       # 7 x 7 3 x 3: k-group kernel with select-based taps
+])
+def test_dgrad_with_batch_norm_backward_sums_in_its_epilogue(B, C, H, W, Co, k, addend):
+    """capmi_igemm_nt_bnsum (EPI 7): the data gradient of a convolution with the completed tensor's ReLU mask as bits, bit-identical
+    to capmi_igemm_nt with the same mask, and the batch-norm backward sums of that tensor's layer -- sum dz, sum dz * xhat over the
+    STORED values -- in the four accumulator rows (default) or, deterministic mode, added to red in a fixed order."""
+    _lib, tdt, code = _env()
+    L = _lib.lib()
+    pad = (k - 1) // 2
+    rng = np.random.RandomState(B + C + Co + k)
+    M = B * H * W
+    dy = rnd(rng.standard_normal((M, Co)), 'bf16')                                  # gradient w.r.t. the conv output [B,H,W,Co]
+    wT = rnd(rng.standard_normal((C, k, k, Co)) / np.sqrt(Co * k * k), 'bf16')      # data-gradient form [Cin][kh][kw][Cout]
+    base = rnd(rng.standard_normal((M, C)), 'bf16') if addend else None
+    mask = rng.uniform(size=(M, C)) > 0.4
+    bits = np.packbits(mask.reshape(-1), bitorder='little')
+    raw = rnd(rng.standard_normal((M, C)) * 1.5 + 0.3, 'bf16')
+    mean = (rng.standard_normal(C) * 0.3).astype(np.float32)
+    inv = (np.abs(rng.standard_normal(C)) + 0.5).astype(np.float32)
+    DY, WT = dev(dy, torch.bfloat16), dev(wT, torch.bfloat16)
+    BITS = torch.as_tensor(bits).to(DEV)
+    RAW, MU, IS = dev(raw, torch.bfloat16), dev(mean, torch.float32), dev(inv, torch.float32)
+    _KEEP.append(BITS)
+    g = _lib.ConvGeom(B, H, W, Co, H, W, k, k, 1, 1, k - 1 - pad, Co)
+    K = k * k * Co
+    R = L.capmi_igemm_nt_bnsum_part_rows(g, C, _lib.BF16)
+    assert R in (64, 128), R
+    dact = _lib.ACT_RELU | _lib.DACT_BITMASK
+
+    def fresh():
+        t = dev(base, torch.bfloat16).clone() if addend else torch.zeros((M, C), dtype=torch.bfloat16, device=DEV)
+        _KEEP.append(t)
+        return t
+    ref = fresh()
+    _lib.call('capmi_igemm_nt', p(DY), p(WT), p(ref), g, C, K, C, None, p(ref) if addend else None, C, p(BITS), C, None, 0, dact, 0, _lib.BF16, stream())
+    dz = host(ref)
+    want = np.concatenate([dz.sum(0), (dz * (raw - mean.astype(np.float64)) * inv.astype(np.float64)).sum(0)])
+    scale = np.abs(want).max()
+    nparts = (M + R - 1) // R
+    PARTS = torch.full((nparts * 2 * C,), float('nan'), device=DEV)
+    ACC = torch.zeros((4, 2 * C), device=DEV)
+    RED = torch.zeros(2 * C, device=DEV)
+    _KEEP.extend([PARTS, ACC, RED])
+    out = fresh()
+    sym = _lib.probe_kernel('capmi_igemm_nt_bnsum', p(DY), p(WT), p(out), g, C, K, C, p(out) if addend else None, C, p(BITS), C, dact,
+                            p(RAW), p(MU), p(IS), p(ACC), p(PARTS), p(RED), _lib.BF16)[0]
+    assert ', 7>' in sym, sym                     # the sums epilogue class, whatever the kernel family
+    _lib.call('capmi_igemm_nt_bnsum', p(DY), p(WT), p(out), g, C, K, C, p(out) if addend else None, C, p(BITS), C, dact,
+              p(RAW), p(MU), p(IS), p(ACC), p(PARTS), p(RED), _lib.BF16, stream())
+    assert torch.equal(out, ref), 'the data gradient itself must not change'
+    got = host(ACC).sum(0)
+    assert np.abs(got - want).max() <= 2e-4 * scale + 1e-3, (np.abs(got - want).max(), scale)
+    assert float(host(RED).max()) == 0.0           # default mode leaves red to capmi_bn_bwd_apply_spread
+    prev = _lib.set_deterministic(True)
+    try:
+        reds = []
+        for _ in range(2):
+            out2, red2 = fresh(), torch.zeros(2 * C, device=DEV)
+            _KEEP.append(red2)
+            _lib.call('capmi_igemm_nt_bnsum', p(DY), p(WT), p(out2), g, C, K, C, p(out2) if addend else None, C, p(BITS), C, dact,
+                      p(RAW), p(MU), p(IS), p(ACC), p(PARTS), p(red2), _lib.BF16, stream())
+            assert torch.equal(out2, ref)
+            reds.append(host(red2))
+        np.testing.assert_array_equal(reds[0], reds[1])
+        assert np.abs(reds[0] - want).max() <= 2e-4 * scale + 1e-3
+    finally:
+        _lib.set_deterministic(prev)
+
+
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('M,N,K', [(1216, 40, 48), (64, 264, 136), (5000, 16, 24), (333, 1000, 32)])
 def test_fc_wgrad_and_colsum(dtype, M, N, K):

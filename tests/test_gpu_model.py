@@ -151,9 +151,9 @@ def test_f32_greedy_ids_bit_exact(attention):
     assert np.abs(pe['conv9_bn_mean'] - oracle.p['conv9_bn_mean']).max() < 1e-3
 
 
-def test_graph_replay_equals_eager():
-    """hipGraph replay of the captured fwd+bwd launch sequence reproduces the eager launches
-    (differences: only the order of f32 atomic accumulations)."""
+def test_graph_replay_equals_eager(deterministic):
+    """hipGraph replay of the captured fwd+bwd launch sequence reproduces the eager launches -- bit for bit in deterministic
+    mode (every f32 atomic accumulation has a fixed-order twin there, include/capmi.h), like the other schedule tests."""
     ocfg, ecfg = _cfgs('mobilenetv2', 'slots', 'f32', S=96)
     B = 6
     params, image, caption = _data(ocfg, B, seed=9)
@@ -161,12 +161,10 @@ def test_graph_replay_equals_eager():
     for it in range(3):       # call 1 warms up + captures, calls 2-3 replay the hipGraph
         l1 = float(e1.forward_backward(image, caption).cpu()[0])
         l2 = float(e2.forward_backward(image, caption).cpu()[0])
-        assert abs(l1 - l2) <= 2e-5, (it, l1, l2)
+        assert l1 == l2, (it, l1, l2)
         g1, g2 = e1.export_reference_grads(), e2.export_reference_grads()
-        gscale = max(np.abs(g).max() for g in g1.values())
         for k in g1:
-            floor = 1e-6 * gscale * np.sqrt(g1[k].size)
-            assert np.linalg.norm(g1[k] - g2[k]) <= 1e-2 * np.linalg.norm(g1[k]) + floor, (it, k)
+            np.testing.assert_array_equal(g1[k], g2[k], err_msg='%s (call %d)' % (k, it))
     # the forward plan replays from a hipGraph (a laned backward plan is launched on two streams instead)
     assert any(str(k).startswith('graph') and v for k, v in e2._train[B].items())
     # full steps through the graph path stay finite and reduce the loss

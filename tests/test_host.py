@@ -467,3 +467,40 @@ def test_no_lds_dma_refill_over_unretired_fragment_reads():
                           os.path.join(root, 'myimagecaptioningmodel_amd', 'csrc', 'igemm.hip')], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().endswith('0 kernels flagged'), out.stdout[-2000:]
+
+
+@pytest.mark.parametrize('which', ['configs2', 'configs3'])
+def test_gradient_bucket_plan_of_the_data_parallel_configs_at_world_eight(which):
+    """BASELINE configs[2] (ResNet-50 + 512-d decoder, 256 images over 8 GPUs) and configs[3] (ResNet-101 + 2-layer 1024-d
+    decoder, 512 over 8): the bucket plan OverlappedTrainer exchanges per step -- it depends on the parameter layout only, so
+    it is checked here without a GPU.  Buckets tile the trainable range in backward-completion order (decoder first), are cut
+    at layer boundaries only, every one but the tail is >= 32 MiB, the tail (the only all-reduce nothing can hide) is a few
+    MB, the payload is what SURVEY.md 8(e) budgets, and the 1/N of ParallelExecutor's CoeffNumDevice (train.py:121-124) is the
+    Adam kernel's gradient scale at world 8."""
+    import torch
+    import bench
+    from myimagecaptioningmodel_amd import default_cfg, dp
+    from myimagecaptioningmodel_amd.params import ParamStore
+    workload, per_gpu = (bench.WORKLOAD, 32) if which == 'configs2' else (bench.WORKLOAD_CFG3, 64)
+    world = 8
+    cfg = default_cfg(batch_size=per_gpu * world, sample_count=0, **workload)
+    st = ParamStore(cfg, torch.device('cpu'))
+    plan = dp.bucket_plan(st)
+    cuts = dp.bucket_cut_points(st)
+    r = plan.ranges
+    assert r[0][0] == 0 and r[-1][1] == st.trainable_size == st.size
+    assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    assert all(e in cuts or e == st.trainable_size for _, e in r)
+    assert r[0][1] >= st.decoder_size                                  # the decoder's gradients are final first: they open the exchange
+    mb = [(e - b) * 4 / 2 ** 20 for b, e in r]
+    assert all(m >= 32.0 for m in mb[:-2]) and mb[-1] <= 4.5 and mb[-1] >= 2.0, mb
+    total_mb = st.trainable_size * 4 / 1e6
+    assert (140 < total_mb < 150) if which == 'configs2' else (390 < total_mb < 410), total_mb      # f32 payload: 146 MB / 398 MB per step
+    assert len(r) == (5 if which == 'configs2' else 7), (len(r), mb)
+    # 1/N: Adam on the SUM of eight identical per-rank gradients with grad_scale 1/8 == Adam on one of them
+    from oracle import ops
+    p0 = np.linspace(-1, 1, 64)
+    g = np.cos(np.arange(64.0))
+    a, _, _ = ops.adam_update(p0, (8 * g) * (1.0 / world), np.zeros(64), np.zeros(64), 1e-3, 1)
+    b, _, _ = ops.adam_update(p0, g, np.zeros(64), np.zeros(64), 1e-3, 1)
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-15)

@@ -8,32 +8,77 @@ from oracle.arch import encoder_ops
 from oracle import model as om
 
 
-def forward_loss(cfg, params, image, caption):
-    """params: dict name -> torch tensor (requires_grad where wanted), reference layouts."""
+def _bf16(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _RoundValue(torch.autograd.Function):
+    """y = bf16(x) in the forward pass, identity in the backward pass: a tensor STORED in bf16."""
+    @staticmethod
+    def forward(ctx, x):
+        return _bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundGrad(torch.autograd.Function):
+    """Identity in the forward pass, bf16(g) in the backward pass: a GRADIENT buffer stored in bf16."""
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _bf16(g)
+
+
+STORAGE_POINTS = ('w', 'img', 'raw', 'act', 'dy', 'dz', 'feat_grad')
+
+
+def forward_loss(cfg, params, image, caption, rounding=()):
+    """params: dict name -> torch tensor (requires_grad where wanted), reference layouts.
+    rounding: the ENCODER storage points rounded to bf16 the way the bf16 engine stores them (tools/bf16_attribution.py,
+    tests/test_bf16_attribution.py) -- 'w' conv filters (the bf16 shadow), 'img' the feed, 'raw' conv outputs (the batch
+    statistics still come from the unrounded accumulators, as in the conv epilogue), 'act' the activated tensors, 'dy' the
+    gradient buffers of the activated tensors, 'dz' the gradients w.r.t. the conv outputs (the weight-gradient / data-gradient
+    operand), 'feat_grad' only the gradient the decoder hands to the encoder output.  Empty: the plain graph."""
     p = params
+    rv = lambda key, x: _RoundValue.apply(x) if key in rounding else x
+    rg = lambda key, x: _RoundGrad.apply(x) if key in rounding else x
     enc, enc_out, C = encoder_ops(cfg['encoder'])
-    t = {0: image}
+    uses = {}
+    for op in enc:
+        for s_ in ((op[2],) if op[0] == 'conv_bn' else (op[1], op[2]) if op[0] == 'add' else (op[1],)):
+            uses[s_] = uses.get(s_, 0) + 1
+    # a linear conv + batch norm whose only reader is a residual add is never stored (the add rides in its bn_apply)
+    unstored = {op[2] for op in enc if op[0] == 'add' and uses.get(op[2], 0) == 1}
+    t = {0: rv('img', image)}
     for op in enc:
         if op[0] == 'conv_bn':
             _, name, src, dst, cin, cout, k, stride, pad, groups, act = op
-            y = F.conv2d(t[src], p[name + '_weights'], None, stride, pad, 1, groups)
+            y = F.conv2d(t[src], rv('w', p[name + '_weights']), None, stride, pad, 1, groups)
+            y = rg('dz', y)
             mean = y.mean(dim=(0, 2, 3), keepdim=True)
             var = y.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+            if 'raw' in rounding:       # the stored copy is rounded, the statistics are those of the f32 accumulators
+                y = y + (_bf16(y) - y).detach()
             y = (y - mean) / torch.sqrt(var + 1e-5)
             y = y * p[name + '_bn_scale'][None, :, None, None] + p[name + '_bn_offset'][None, :, None, None]
             if act == 'relu6':
                 y = torch.clamp(y, 0, 6)
             elif act == 'relu':
                 y = torch.relu(y)
-            t[dst] = y
+            t[dst] = y if (act is None and dst in unstored) else rg('dy', rv('act', y))
         elif op[0] == 'add':
             _, a, b, dst, act = op
             y = t[a] + t[b]
-            t[dst] = torch.relu(y) if act == 'relu' else y
+            t[dst] = rg('dy', rv('act', torch.relu(y) if act == 'relu' else y))
         else:
             _, src, dst = op
             t[dst] = F.max_pool2d(t[src], 3, 2, 1)
-    feat = t[enc_out]
+    feat = rg('feat_grad', t[enc_out])
     B = feat.shape[0]
     A = feat.reshape(B, C, -1).permute(0, 2, 1)
 
