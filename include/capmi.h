@@ -540,6 +540,9 @@ int capmi_fill_f32(float* p, float value, int64_t n, void* stream);
 #define CAPMI_COMM_ID_BYTES 128
 int capmi_comm_unique_id(void* id_out);
 int capmi_comm_init(void** comm, int nranks, int rank, const void* id);
+/* What RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank): bench.py prints it next to a multi-GPU
+ * number, so that the record proves how many ranks the all-reduce really spanned. */
+int capmi_comm_count(void* comm, int* nranks, int* rank);
 int capmi_comm_destroy(void* comm);
 int capmi_allreduce_bucket(void* comm, float* buf, int64_t n, void* stream);
 /* The same on a bf16 copy of the bucket (capmi_cast of the f32 gradients into a staging buffer; capmi_adam_g16 reads the sum

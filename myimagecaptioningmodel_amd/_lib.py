@@ -152,6 +152,7 @@ SYNC = {
 COMM = {
     'capmi_comm_unique_id': [_p],
     'capmi_comm_init': [_p, _i, _i, _p],      # void** comm, nranks, rank, id
+    'capmi_comm_count': [_p, _p, _p],
     'capmi_comm_destroy': [_p],
 }
 COMM_ID_BYTES = 128
@@ -447,11 +448,14 @@ class Plan:
             patches = [(r + len(head), i, src) for r, i, src in patches]
             body = head + body + tail
         table = (Launch * max(1, len(body)))(*body)
-        return dict(table=table, n=len(body), patches=patches, events=events, used=sorted(used), side=side)
+        return dict(table=table, n=len(body), patches=patches, events=events, used=sorted(used), side=side,
+                    tail_len=2 * len(used - {0}) if lanes else 0)
 
-    def run(self, stream, side=True):
+    def run(self, stream, side=True, tail_events=None):
+        """tail_events: {lane: event of capmi_event_create_timed} recorded at the END of each lane's work, in front of the final
+        join (measurements only: the table goes out as two calls)."""
         lanes = bool(side and self.has_lanes and os.environ.get('CAPMI_LANES', '1') != '0')
-        if os.environ.get('CAPMI_PY_PLAN', '0') == '1':
+        if os.environ.get('CAPMI_PY_PLAN', '0') == '1' and tail_events is None:
             return self._run_py(stream, lanes)
         key = (lanes, len(self.calls))
         c = self._compiled.get(key)
@@ -463,6 +467,16 @@ class Plan:
         if lanes:
             for l, s in c['side']['streams'].items():
                 streams[l] = s.value
+        if tail_events is not None and lanes:
+            k = c['n'] - c['tail_len']
+            if lib().capmi_plan_run(c['table'], k, streams, 3) != 0:
+                raise CapmiError('plan: %s' % last_error())
+            for lane, ev in tail_events.items():
+                lib().capmi_event_record(ev, streams[lane])
+            tail = (Launch * max(1, c['tail_len']))(*[c['table'][i] for i in range(k, c['n'])])
+            if c['tail_len'] and lib().capmi_plan_run(tail, c['tail_len'], streams, 3) != 0:
+                raise CapmiError('plan: %s' % last_error())
+            return
         if lib().capmi_plan_run(c['table'], c['n'], streams, 3) != 0:
             raise CapmiError('plan: %s' % last_error())
 

@@ -614,23 +614,43 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // output row (scattered for a parity class of a strided data gradient) of the lane's row r of row block i
+    auto out_row = [&](int i, int r, bool& valid) -> int64_t {
+        const int rl = i * 16 + fg * 4 + r;
+        valid = rows_full || rl < wcnt;
+        int64_t row = wrow0 + rl;
+        if (EPI != 1 && EPI != 8 && EPI != 7 && a.g.os > 1 && valid) {  // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
+            const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
+            const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
+            row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
+        }
+        return row;
+    };
+    // EPI 3 / 6 (inference convolution with its residual; data gradient with an addend and the mask already in registers): the
+    // addend runs of ALL rows up front as well -- these epilogues have no other load, and the batches of four rows cost one
+    // exposed memory latency each (TM of them per workgroup)
+    constexpr bool PA_ALL = DENSE && (EPI == 3 || EPI == 6);
+    RunT paa[PA_ALL ? TM : 1][4];
+    if constexpr (PA_ALL) {
+        if (addend && col0 < a.N) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    bool ok;
+                    const int64_t row = out_row(i, r, ok);
+                    if (ok) paa[i][r] = *reinterpret_cast<const RunT*>(addend + row * a.ld_addend + col0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     if (col0 < a.N) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             int64_t rows[4];
             bool valid[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rl = i * 16 + fg * 4 + r;
-                valid[r] = rows_full || rl < wcnt;
-                int64_t row = wrow0 + rl;
-                if (EPI != 1 && EPI != 8 && EPI != 7 && a.g.os > 1 && valid[r]) {  // scatter: GEMM row (b,i,j) -> pixel (b, i*os+oh0, j*os+ow0) of [B,Hof,Wof]
-                    const int mm = (int)row, bb = fdiv(mm, a.fd_hw), rem = mm - bb * a.fd_hw.d;
-                    const int ii = fdiv(rem, a.fd_w), jj = rem - ii * a.fd_w.d;
-                    row = ((int64_t)bb * a.g.Hof + ii * a.g.os + a.g.oh0) * a.g.Wof + jj * a.g.os + a.g.ow0;
-                }
-                rows[r] = row;
-            }
+            for (int r = 0; r < 4; ++r) rows[r] = out_row(i, r, valid[r]);
             if (DENSE || vec_ok) {
                 // all loads of the four rows first (the output may alias the addend, so the compiler cannot
                 // hoist a row's loads over the previous row's store by itself: one memory latency, not four)
@@ -640,7 +660,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                 RunT pa[4], py[4], px[4];
 #pragma unroll
                 for (int r = h; r < h + RB; ++r) {
-                    if (EPI != 1 && EPI != 8 && EPI != 5 && addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
+                    if (!PA_ALL && EPI != 1 && EPI != 8 && EPI != 5 && addend && valid[r]) pa[r] = *reinterpret_cast<const RunT*>(addend + rows[r] * a.ld_addend + col0);
                     if constexpr (EPI == 6) {
                         if (!pmask && valid[r]) py[r][0] = bits_to_elem<T>(reinterpret_cast<const uint8_t*>(a.ysaved)[(rows[r] * a.ld_saved + col0) >> 3]);
                     } else if (EPI != 7 && EPI != 1 && EPI != 8 && EPI != 3 && EPI != 5 && a.dact && valid[r]) py[r] = *reinterpret_cast<const RunT*>(ysaved + rows[r] * a.ld_saved + col0);
@@ -654,7 +674,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
                     for (int j = 0; j < TN; ++j) v[j] = acc[i][j][r];
                     if (EPI != 1 && EPI != 8 && EPI != 5 && addend) {
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) v[j] += (float)pa[r][j];
+                        for (int j = 0; j < TN; ++j) v[j] += PA_ALL ? (float)paa[i][r][j] : (float)pa[r][j];
                     }
                     if constexpr (EPI == 0) act_run<TN>(v, a.act);
                     if constexpr (EPI == 2) {

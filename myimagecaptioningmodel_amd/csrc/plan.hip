@@ -168,6 +168,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -187,6 +189,8 @@ int rccl_load() {
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
     g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))dlsym(h, "ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))dlsym(h, "ncclCommUserRank");
     g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
     CAPMI_CHECK(g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.GetErrorString,
                 "capmi_comm: librccl.so lacks an expected symbol");
@@ -216,6 +220,17 @@ extern "C" int capmi_comm_init(void** comm, int nranks, int rank, const void* id
     ncclResult_t r = g_rccl.CommInitRank(&c, nranks, uid, rank);
     CAPMI_CHECK(r == ncclSuccess, "capmi_comm_init: %s", g_rccl.GetErrorString(r));
     *comm = (void*)c;
+    return 0;
+}
+
+/* What RCCL itself says about the communicator: ranks in it and this process's rank (ncclCommCount / ncclCommUserRank). */
+extern "C" int capmi_comm_count(void* comm, int* nranks, int* rank) {
+    CAPMI_CHECK(comm && nranks && rank, "capmi_comm_count: null pointer");
+    CAPMI_CHECK(g_rccl.CommCount && g_rccl.CommUserRank, "capmi_comm_count: librccl.so lacks ncclCommCount / ncclCommUserRank");
+    ncclResult_t r = g_rccl.CommCount((ncclComm_t)comm, nranks);
+    CAPMI_CHECK(r == ncclSuccess, "capmi_comm_count: %s", g_rccl.GetErrorString(r));
+    r = g_rccl.CommUserRank((ncclComm_t)comm, rank);
+    CAPMI_CHECK(r == ncclSuccess, "capmi_comm_count: %s", g_rccl.GetErrorString(r));
     return 0;
 }
 

