@@ -601,16 +601,21 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
     // EPI 7: the batch-norm operand (the layer's conv output) of EVERY row of the lane, requested up front -- the fragment
     // registers of the main loop are dead by now -- so the epilogue pays one memory latency for them, not one per row batch
     // (measured: +10.7 us per launch with the loads inside the batches, 2 rows at a time)
+    // The sums are taken in a SECOND pass over the accumulators (which then hold the stored values), behind all the stores:
+    // nothing in the store pass waits for these loads.  With an addend (whose own loads come first) they are issued row block
+    // by row block behind that block's stores, as its addend registers fall free.
     RunT pxa[EPI == 7 ? TM : 1][4];
+    auto load_px = [&](int i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rl = i * 16 + fg * 4 + r;
+            if (rows_full || rl < wcnt) pxa[i][r] = *reinterpret_cast<const RunT*>(rx0 + (int64_t)(wrow0 + rl) * a.N + col0);
+        }
+    };
     if constexpr (EPI == 7) {
-        if (col0 < a.N) {
+        if (col0 < a.N && !a.addend) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rl = i * 16 + fg * 4 + r;
-                    if (rows_full || rl < wcnt) pxa[i][r] = *reinterpret_cast<const RunT*>(rx0 + (int64_t)(wrow0 + rl) * a.N + col0);
-                }
+            for (int i = 0; i < TM; ++i) load_px(i);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -629,7 +634,7 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
     // EPI 3 / 6 (inference convolution with its residual; data gradient with an addend and the mask already in registers): the
     // addend runs of ALL rows up front as well -- these epilogues have no other load, and the batches of four rows cost one
     // exposed memory latency each (TM of them per workgroup)
-    constexpr bool PA_ALL = DENSE && (EPI == 3 || EPI == 6);
+    constexpr bool PA_ALL = DENSE && (EPI == 3 || EPI == 6 || EPI == 7);
     RunT paa[PA_ALL ? TM : 1][4];
     if constexpr (PA_ALL) {
         if (addend && col0 < a.N) {
@@ -726,11 +731,14 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             const float dz = to_f32(from_f32<T>(v[j]));     // the value the BN apply pass reads back
+                            acc[i][j][r] = dz;
                             s1[j] += dz;
-                            s2[j] += dz * ((float)pxa[i][r][j] - mu0[j]);  // * invstd below, once per column
                         }
                     }
                 }
+                }
+                if constexpr (EPI == 7) {
+                    if (a.addend) load_px(i);
                 }
             } else if constexpr (!DENSE) {
 #pragma unroll
@@ -866,6 +874,16 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
         if (CAPMI_FIN && a.fin_cnt) nt_fin_tail<BM, BN>(a, m0, n0, sred);
     }
     if constexpr (EPI == 7) {
+        if (col0 < a.N) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (!(rows_full || i * 16 + fg * 4 + r < wcnt)) continue;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) s2[j] += acc[i][j][r] * ((float)pxa[i][r][j] - mu0[j]);  // * invstd below, once per column
+                }
+        }
         // (first barrier: every wave is done with whatever lived at the start of the staging area -- the k-group exchange)
         lds_barrier();
 #pragma unroll

@@ -212,4 +212,7 @@ def test_forward_statistics_path_in_the_engine(monkeypatch):
     assert abs(l1 - l0) <= 2e-2, (l1, l0)            # (random initialisation: the bf16 engine itself is held to 5e-2 against the oracle)
     for n in p0:
         if n.endswith(('_bn_mean', '_bn_variance')):
-            assert np.abs(p1[n] - p0[n]).max() <= 1e-2 * max(1.0, np.abs(p0[n]).max()), n
+            # the first layers see the same input on both paths: one-pass f32 sums against the exact merge; deeper layers see
+            # what 50 batch norms over 256-16k samples make of those differences at random initialisation
+            tol = 1e-4 if n.startswith(('res_conv1', 'res2_1_branch2a', 'res2_1_branch1')) else 5e-2
+            assert np.abs(p1[n] - p0[n]).max() <= tol * max(1.0, np.abs(p0[n]).max()), n
