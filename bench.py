@@ -79,6 +79,30 @@ def pmc_traffic(symbol):
     return round(row['hbm_bytes_per_launch'] / 1e6, 3), source
 
 
+def rocprof_row(symbol):
+    """The row of `symbol` in the newest committed `rocprofv3 --kernel-trace --stats` summary of this command
+    (profiles/rNN_bench_kernel_stats.csv): (average launch duration in us, calls, source) or (None, None, source)."""
+    import csv
+    import glob
+    import re
+    files = [f for f in glob.glob(os.path.join(ROOT, 'profiles', 'r*_bench_kernel_stats.csv')) if re.match(r'r\d+_', os.path.basename(f))]
+    if not files:
+        return None, None, None
+    f = max(files, key=lambda x: int(re.match(r'r(\d+)_', os.path.basename(x)).group(1)))
+    src = dict(file=os.path.relpath(f, ROOT))
+    pmc = f.replace('_bench_kernel_stats.csv', '_pmc_traffic.json')
+    if os.path.exists(pmc):
+        try:
+            src['recorded_on'] = json.load(open(pmc)).get('head')
+        except Exception:
+            pass
+    for r in csv.DictReader(open(f)):
+        if r['Name'] == symbol:
+            return float(r['AverageNs']) / 1e3, int(r['Calls']), src
+    src['missing'] = 'no row for this symbol'
+    return None, None, src
+
+
 def roofline_of(symbol, s, steps):
     """Both roofline fractions of one kernel symbol from its in-model time: against HBM (algorithmic bytes) and -- for a GEMM --
     against the dense bf16 MFMA peak (algorithmic flops).  `bound` names the roof the kernel's intensity puts it under (the
@@ -470,12 +494,28 @@ def main():
                     timing='HIP events around every launch on the stream it is launched on, the step running on its two lanes (%d runs); '
                            'minus the interval an event pair adds by itself, calibrated on an idle device' % R,
                     event_pair_overhead_us=round(over * 1e3, 2))
+        # cross-check against the committed rocprofv3 summary of the same command: the same algorithmic bytes / flops over ITS
+        # average duration.  HIP events on the low-priority side lane measure from the moment a kernel is ELIGIBLE (its
+        # predecessor on the lane has ended) to its end, rocprofv3 from the moment it is dispatched: for side-lane kernels
+        # (the weight gradients) the event figure is the larger by the dispatch wait behind the main lane's kernels; for
+        # main-lane kernels the two agree within a few per cent (see roofline_main_lane_gemm).
+        avg_us, calls, src = rocprof_row(name)
+        if avg_us:
+            per = roof['algorithmic_per_launch']
+            roof['rocprof_check'] = dict(avg_launch_us=round(avg_us, 2), calls=calls,
+                                         frac_hbm=round(per['MB'] * 1e6 / (avg_us * 1e-6) / 1e9 / profiling.PEAK_HBM_GBPS, 4),
+                                         frac_mfma=round(per['GFLOP'] * 1e9 / (avg_us * 1e-6) / 1e12 / profiling.PEAK_MFMA_TFLOPS['bf16'], 4), source=src)
+        elif src:
+            roof['rocprof_check'] = dict(source=src)
         out['roofline'] = roof
         gemm = [(k, v) for k, v in top if v['flops'] > 0]
         # the largest MAIN-lane GEMM symbol next to it (the dominant symbol is a side-lane weight gradient)
         main_gemm = next(((k, v) for k, v in gemm if 0 in v['lanes'] and k != name), None)
         if main_gemm is not None:
             out['roofline_main_lane_gemm'] = roofline_of(main_gemm[0], main_gemm[1], R)
+            avg_us, calls, src = rocprof_row(main_gemm[0])
+            if avg_us:
+                out['roofline_main_lane_gemm']['rocprof_check'] = dict(avg_launch_us=round(avg_us, 2), calls=calls, source=src)
         g_fl, g_ms = sum(v['flops'] for _, v in gemm), sum(v['ms'] for _, v in gemm)
         out['gemm_mfma_frac'] = round(g_fl / (g_ms * 1e-3) / 1e12 / profiling.PEAK_MFMA_TFLOPS['bf16'], 4)
         out['gemm_summary'] = dict(gflop_per_step=round(g_fl / R / 1e9, 1), gemm_kernel_ms_per_step=round(g_ms / R, 3),

@@ -157,6 +157,7 @@ COMM = {
 }
 COMM_ID_BYTES = 128
 
+NLANES = 4                # lanes of a plan: 0 dependency chain, 1 weight gradients, 2 communication + optimizer, 3 projection-shortcut backward
 PLAN_MAX_ARGS = 24
 PLAN_LAUNCH, PLAN_RECORD, PLAN_WAIT = 0, 1, 2
 
@@ -394,7 +395,8 @@ class Plan:
                 # lane 1 (weight gradients): lowest priority, it fills the main lane's gaps; lane 2 (all-reduce +
                 # optimizer): CAPMI_COMM_PRIORITY (default 0)
                 s, ev = ctypes.c_void_p(), ctypes.c_void_p()
-                prio = int(os.environ.get('CAPMI_SIDE_PRIORITY', '-1')) if lane == 1 else int(os.environ.get('CAPMI_COMM_PRIORITY', '0'))
+                prio = (int(os.environ.get('CAPMI_SIDE_PRIORITY', '-1')) if lane == 1 else int(os.environ.get('CAPMI_COMM_PRIORITY', '0')) if lane == 2
+                        else int(os.environ.get('CAPMI_SHORTCUT_PRIORITY', '0')))
                 if L.capmi_stream_create(ctypes.byref(s), prio) or L.capmi_event_create(ctypes.byref(ev)):
                     raise CapmiError('lane %d: %s' % (lane, last_error()))
                 side['streams'][lane], side['join'][lane] = s, ev
@@ -463,21 +465,21 @@ class Plan:
             c = self._compiled[key] = self._compile(lanes)
         for row, slot, src in c['patches']:
             c['table'][row].args[slot] = _patch_bits(src)
-        streams = (ctypes.c_void_p * 3)(stream, stream, stream)
+        streams = (ctypes.c_void_p * NLANES)(*([stream] * NLANES))
         if lanes:
             for l, s in c['side']['streams'].items():
                 streams[l] = s.value
         if tail_events is not None and lanes:
             k = c['n'] - c['tail_len']
-            if lib().capmi_plan_run(c['table'], k, streams, 3) != 0:
+            if lib().capmi_plan_run(c['table'], k, streams, NLANES) != 0:
                 raise CapmiError('plan: %s' % last_error())
             for lane, ev in tail_events.items():
                 lib().capmi_event_record(ev, streams[lane])
             tail = (Launch * max(1, c['tail_len']))(*[c['table'][i] for i in range(k, c['n'])])
-            if c['tail_len'] and lib().capmi_plan_run(tail, c['tail_len'], streams, 3) != 0:
+            if c['tail_len'] and lib().capmi_plan_run(tail, c['tail_len'], streams, NLANES) != 0:
                 raise CapmiError('plan: %s' % last_error())
             return
-        if lib().capmi_plan_run(c['table'], c['n'], streams, 3) != 0:
+        if lib().capmi_plan_run(c['table'], c['n'], streams, NLANES) != 0:
             raise CapmiError('plan: %s' % last_error())
 
     def _run_py(self, stream, lanes):

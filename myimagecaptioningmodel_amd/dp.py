@@ -227,7 +227,7 @@ class OverlappedTrainer:
                     # BEHIND ncclCommInitRank -- the slow hardware-queue assignment described above.  Refuse it loudly.
                     raise RuntimeError('dp.OverlappedTrainer: an RCCL communicator was created on %s before the plan lanes; build the '
                                        'trainer (or call _lib.Plan._lane_streams({1, 2})) before any NativeComm' % engine.device)
-                Plan._lane_streams({1, 2})
+                Plan._lane_streams({1, 2, 3})
             nc = NativeComm(engine.pg, dist.get_rank(engine.pg), dist.get_world_size(engine.pg), engine.device)
             if nc.ok and os.environ.get('CAPMI_NATIVE_COMM') == '2':       # timing experiment: communicator created, not used
                 self._unused_comm = nc
@@ -292,6 +292,9 @@ class OverlappedTrainer:
             if sub.has_lanes:                       # the segment's weight gradients (lane 1) are part of the bucket
                 step.record(('bucket', i, 1), 1)
                 step.wait(('bucket', i, 1), 2)
+                if any(getattr(fn, 'lane', 0) == 3 for fn, _, _ in sub.calls if fn is not None):      # ... and a projection shortcut's batch-norm gradients (lane 3)
+                    step.record(('bucket', i, 3), 3)
+                    step.wait(('bucket', i, 3), 2)
             if g16 is not None:                     # bf16 payload: cast -> all-reduce -> Adam reads the bf16 sum
                 step.add('capmi_cast', st.grad.data_ptr() + b * 4, g16.data_ptr() + b * 2, e - b, BF16, lane=2)
                 step.add('capmi_allreduce_bucket_bf16', self.native_comm.comm, g16.data_ptr() + b * 2, e - b, lane=2)

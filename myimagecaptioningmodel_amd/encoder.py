@@ -141,6 +141,10 @@ class EncoderRunner:
         self.draws = [z((max_elems,)) for _ in range(int(os.environ.get('CAPMI_RING', '6')))] if need_backward else None
         self.draw = self.draws[0] if need_backward else None
         self.overlap_wgrad = True
+        # lane of a projection shortcut's backward: 1 = the weight-gradient lane (default), 3 = a lane of its own (measured equal
+        # on one GPU: 7.64-7.71 against 7.69-7.70 ms per step -- tools/lane_gaps.py had shown the main lane waiting for it under
+        # instrumentation only)
+        self.shortcut_lane = int(os.environ.get('CAPMI_SHORTCUT_LANE', '1'))
         self.overlap_forward = os.environ.get('CAPMI_FWD_SIDE', '1') != '0'     # projection shortcuts of the forward pass on the side lane
         self.draw_side = z((max_elems,)) if need_backward else None     # raw-output gradient of a projection shortcut (side lane)
         ws = 0
@@ -522,6 +526,7 @@ class EncoderRunner:
 
         shortcut_done = set()           # outputs of projection shortcuts whose backward already ran on the aliased gradient
         ring_pos, ring_user = [0], [None] * len(self.draws)
+        side_draw_user = [None]         # the projection shortcut whose weight gradient (lane 1) read draw_side last
         side_written = {}               # tensor -> event key: its gradient's first writer ran on the side lane
         conv_of_out = {}                # tensor id -> the ConvBN whose (fused-add) output it is
         for o in self.enc.ops:
@@ -560,10 +565,15 @@ class EncoderRunner:
                     shortcut_done.add(op.dst)
                 # a projection shortcut's whole backward (BN backward, both gradients) is independent of the
                 # branch2c..2a chain: it runs on the side lane, between two events
-                ln = 1 if (id(op) in early and self.overlap_wgrad) else 0
+                # ... on a lane of ITS OWN (3): on the weight-gradient lane it queued behind whatever weight gradients that lane
+                # still owed, and the main lane then waited for it at the block's first convolution -- 40-200 us per stage
+                # (tools/lane_gaps.py: `wait pdone/...` binding).  Only its weight gradient stays on lane 1.
+                ln = self.shortcut_lane if (id(op) in early and self.overlap_wgrad) else 0
                 if ln:
                     plan.record(('blk', op.name), 0)
-                    plan.wait(('blk', op.name), 1)
+                    plan.wait(('blk', op.name), ln)
+                    if ln != 1 and side_draw_user[0] is not None:        # draw_side is still the operand of the previous shortcut's weight gradient
+                        plan.wait(('wgrad', side_draw_user[0]), ln)
                 ho, wo, c = self.shape[op.dst]
                 M = B * ho * wo
                 bn = self.bn[op.dst]
@@ -639,9 +649,9 @@ class EncoderRunner:
                 else:
                     plan.add('capmi_bn_bwd_apply', _p(dy), _p(raw), _p(y), _p(bn['mean']), _p(bn['invstd']),
                              _p(st.view(op.name + '_bn_scale')), _p(red), _p(draw), 0, _p(dres), dres_acc, M, c, act, code, lane=ln)
-                if wl and not ln:
-                    plan.record(('dz', op.name), 0)
-                    plan.wait(('dz', op.name), 1)
+                if wl and ln != wl:
+                    plan.record(('dz', op.name), ln)
+                    plan.wait(('dz', op.name), wl)
                 dwt = st.gview(op.name + '_weights')
                 if op.src == 0:
                     plan.add('capmi_igemm_tn_wgrad', _p(self.s2d), _p(draw), _p(dwt), self._stem_geom(op), c, c, self.kpad_of(op),
@@ -665,6 +675,9 @@ class EncoderRunner:
                     plan.add('capmi_igemm_tn_wgrad', _p(self.act[op.src]), _p(draw), _p(dwt), g, c, c, K, _p(wgrad_workspace(self.dev, wl)), WGRAD_WS_BYTES, code, lane=wl)
                     if wl and not ln:
                         plan.record(('wgrad', op.name), 1)
+                    elif wl and ln != wl:
+                        plan.record(('wgrad', op.name), wl)
+                        side_draw_user[0] = op.name
                     t = op.src
                     dx = self.grad[t]
                     src_act = tensor_act.get(t)
@@ -748,7 +761,7 @@ class EncoderRunner:
                         plan.add('capmi_igemm_nt_group', calls, len(launches), code, lane=ln)
                     written.add(t)
                     if ln:
-                        plan.record(('pdone', op.name), 1)
+                        plan.record(('pdone', op.name), ln)
                         side_written[t] = ('pdone', op.name)
                     if is_last and (mask or src_act is None):
                         premasked.add(t)

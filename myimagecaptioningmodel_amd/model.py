@@ -71,7 +71,7 @@ class CaptionEngine:
         # the side lane's HIP stream now, before anything else in the process creates streams (hardware-queue assignment
         # follows creation order: see dp.OverlappedTrainer)
         with torch.cuda.device(self.device):
-            Plan._lane_streams({1})
+            Plan._lane_streams({1, 3})
         self._train = {}      # batch size -> compiled train program
         self._eval = {}
         self.shadows_dirty = True
@@ -443,6 +443,9 @@ class CaptionEngine:
                 fused.extend(piece(at, idx))
                 fused.record(('opt', 'head', n), 0)
                 fused.wait(('opt', 'head', n), 1)
+                if any(getattr(fn, 'lane', 0) == 3 for fn, _, _ in bwd.calls[:idx] if fn is not None):
+                    fused.record(('opt', 'head3', n), 3)        # (batch-norm gradients of a projection shortcut are written on lane 3)
+                    fused.wait(('opt', 'head3', n), 1)
                 optimizer_range(fused, lo, off, 1)
                 shadow_range(fused, lo, off, 1)
                 at, lo = idx, off

@@ -110,6 +110,14 @@ def test_two_lane_schedule_equals_the_single_stream_order(full, monkeypatch, det
     g1 = eng1.store.grad[:eng1.store.trainable_size]
     assert l1 == l0, (l0, l1)
     assert torch.equal(g1, g0), float((g1 - g0).abs().max())
+    # ... and with the projection shortcuts' backward on a lane of its own (CAPMI_SHORTCUT_LANE=3: four lanes)
+    monkeypatch.delenv('CAPMI_LANES')
+    monkeypatch.setenv('CAPMI_SHORTCUT_LANE', '3')
+    eng3 = CaptionEngine(cfg, device='cuda:0', use_graph=False)
+    eng3.load_reference_params(params)
+    l3 = _loss(eng3, image, cap)
+    assert any(getattr(c[0], 'lane', 0) == 3 for c in eng3._train[image.shape[0]]['bwd'].calls if c[0] is not None)
+    assert l3 == l0 and torch.equal(eng3.store.grad[:eng3.store.trainable_size], g0)
 
 
 def test_epilogue_classes_equal_the_general_epilogue_at_full_size(full, deterministic):
