@@ -509,6 +509,11 @@ int capmi_beam_backtrack(const int* tokens, const int* parents, float* out_ids_f
  * grad_scale multiplies g first (1/N of ParallelExecutor's CoeffNumDevice, IC/train.py:121-124). */
 int capmi_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1,
                float b2, float eps, float clip, float grad_scale, void* stream);
+/* capmi_adam followed by capmi_cast of the same range to bf16, as one pass: low16[i] = bf16(updated p[i]) -- the weight shadow
+ * the bf16 kernels read -- written from the registers of the update (IC/train.py:26-31,45: the adam op; the shadow is this
+ * build's bf16 storage of the parameters). */
+int capmi_adam_shadow(float* p, const float* g, float* m, float* v, void* low16, int64_t n, float lr_t, float b1, float b2,
+                      float eps, float clip, float grad_scale, void* stream);
 /* capmi_adam with the gradient read from a bf16 buffer (widened to f32 on load): the consumer of a bucket that was
  * all-reduced in bf16 (capmi_allreduce_bucket_bf16).  Moments and master weights stay f32. */
 int capmi_adam_g16(float* p, const void* g16, float* m, float* v, int64_t n, float lr_t, float b1,

@@ -104,6 +104,7 @@ SIGNATURES = {
     'capmi_softmax_xent_bwd': [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p],
     'capmi_argmax': [_p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_adam': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
+    'capmi_adam_shadow': [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
     'capmi_adam_g16': [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _f, _p],
     'capmi_cast': [_p, _p, _l, _i, _p],
     'capmi_weight_dgrad_form': [_p, _p, _i, _i, _i, _i, _i, _i, _p],

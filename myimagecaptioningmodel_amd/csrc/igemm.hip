@@ -3366,7 +3366,10 @@ static int tn_splits(int M, int N, int K, int bno, int bko, int* per_out) {
     return cdiv(M, per);
 }
 static void tn_tile(int N, int K, int dtype, int* bno, int* bko) {
-    const bool big = dtype == CAPMI_BF16 && N >= 128 && K >= 128;
+    // CAPMI_TN_PAD64=1 (experiment): the LDS-DMA kernel also for 64-wide operands (the 56 x 56 layers of a ResNet, the stem) -- its 128 x 128
+    // tile padded from the zero page (MFMA and DMA slots on zeros are free next to the register-staged kernel's 77 us in the model)
+    static const int pad64 = getenv("CAPMI_TN_PAD64") ? atoi(getenv("CAPMI_TN_PAD64")) : 0;
+    const bool big = dtype == CAPMI_BF16 && ((N >= 128 && K >= 128) || (pad64 && N >= 64 && K >= 64 && N % 8 == 0 && K % 8 == 0));
     *bno = *bko = big ? 128 : 64;
 }
 

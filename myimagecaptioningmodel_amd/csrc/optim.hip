@@ -17,9 +17,11 @@ static inline int bulk_grid(int64_t chunks, int64_t elems) {
     const int g = ew_grid(chunks);
     return (cap > 0 && elems >= (1ll << 23) && g > cap) ? cap : g;
 }
-template <typename G>
+// LOW: also store the updated parameter rounded to bf16 into `low` (the weight shadow the kernels read: capmi_cast of the same
+// range right behind the update would read all of p again)
+template <typename G, bool LOW = false>
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const G* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   int64_t n, float lr_t, float b1, float b2, float eps, float clip, float gscale) {
+                                                   int64_t n, float lr_t, float b1, float b2, float eps, float clip, float gscale, bf16* __restrict__ low = nullptr) {
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         f32x4 pv = reinterpret_cast<f32x4*>(p)[i], gv = adam_load4<G>(g, i);
@@ -35,6 +37,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         reinterpret_cast<f32x4*>(p)[i] = pv;
         reinterpret_cast<f32x4*>(m)[i] = mv;
         reinterpret_cast<f32x4*>(v)[i] = vv;
+        if constexpr (LOW) reinterpret_cast<bf16x4*>(low)[i] = bf16x4{(bf16)pv[0], (bf16)pv[1], (bf16)pv[2], (bf16)pv[3]};
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         int64_t i = n4 * 4 + threadIdx.x;
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         float mm = b1 * m[i] + (1.f - b1) * gg, vv = b2 * v[i] + (1.f - b2) * gg * gg;
         m[i] = mm; v[i] = vv;
         p[i] = p[i] - lr_t * (mm / (sqrtf(vv) + eps));
+        if constexpr (LOW) low[i] = (bf16)p[i];
     }
 }
 extern "C" int capmi_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float b1, float b2, float eps,
@@ -52,6 +56,17 @@ extern "C" int capmi_adam(float* p, const float* g, float* m, float* v, int64_t 
     if (n <= 0) return 0;
     hipLaunchKernelGGL(adam_kernel<float>, dim3(bulk_grid(n / 4 + 1, n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, b1, b2, eps, clip, grad_scale);
     CAPMI_LAUNCH_CHECK("capmi_adam");
+    return 0;
+}
+/* capmi_adam + capmi_cast(p -> low16, bf16) of the same range in one pass: the bf16 weight shadow is written from the registers that
+ * hold the updated parameter (the separate cast read every parameter again: 4 B each, under the bandwidth-bound backward pass). */
+extern "C" int capmi_adam_shadow(float* p, const float* g, float* m, float* v, void* low16, int64_t n, float lr_t, float b1, float b2, float eps,
+                                 float clip, float grad_scale, void* stream) {
+    CAPMI_CHECK(p && g && m && v && low16, "capmi_adam_shadow: null pointer");
+    CAPMI_CHECK(((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16 == 0 && (uintptr_t)low16 % 8 == 0, "capmi_adam_shadow: buffers must be 16-byte (shadow: 8-byte) aligned");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL((adam_kernel<float, true>), dim3(bulk_grid(n / 4 + 1, n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_t, b1, b2, eps, clip, grad_scale, (bf16*)low16);
+    CAPMI_LAUNCH_CHECK("capmi_adam_shadow");
     return 0;
 }
 /* The same update from a bf16 gradient bucket (the data-parallel step's all-reduce payload, capmi_allreduce_bucket_bf16):

@@ -115,6 +115,7 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_gather_rows),
     CAPMI_ENTRY(capmi_beam_backtrack),
     CAPMI_ENTRY(capmi_adam),
+    CAPMI_ENTRY(capmi_adam_shadow),
     CAPMI_ENTRY(capmi_adam_g16),
     CAPMI_ENTRY(capmi_cast),
     CAPMI_ENTRY(capmi_weight_dgrad_form),

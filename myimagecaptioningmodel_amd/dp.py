@@ -300,8 +300,9 @@ class OverlappedTrainer:
                 step.add('capmi_allreduce_bucket_bf16', self.native_comm.comm, g16.data_ptr() + b * 2, e - b, lane=2)
             else:
                 step.add('capmi_allreduce_bucket', self.native_comm.comm, st.grad.data_ptr() + b * 4, e - b, lane=2)
-            eng.plan_adam(step, b, e, lrt, 2, grad_scale=1.0 / eng.world, g16=g16)
-            eng.plan_shadow(step, b, st.size if e == total else e, 2)
+            wrote = eng.plan_adam(step, b, e, lrt, 2, grad_scale=1.0 / eng.world, g16=g16, shadow=True)
+            # (the weight forms of the data gradients are rebuilt under the next forward pass when the forward plan carries them)
+            eng.plan_shadow(step, b, e if wrote else (st.size if e == total else e), 2, cast=not wrote, forms=not prog.get('forms_in_fwd', False))
         return step, lrt
 
     def describe(self, B):

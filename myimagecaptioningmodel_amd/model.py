@@ -184,6 +184,11 @@ class CaptionEngine:
         zero_in_fwd = fwd_enc.has_lanes
         if zero_in_fwd:
             head = Plan()
+            # the data-gradient weight forms of the parameters the last step's optimizer wrote: only the backward pass reads them,
+            # so they are rebuilt HERE, on the side lane under the forward pass -- the backward pass is bound by HBM bytes
+            # (16.8 GB in ~4.2 ms), the forward pass is not (DESIGN.md lesson 60)
+            if os.environ.get('CAPMI_FORMS_IN_FWD', '1') != '0' and need_enc_bwd:
+                head.add('capmi_weight_dgrad_form_batched', _p(self.store.flat), _p(self.wT), _p(self.dgrad_jobs), len(self.dgrad_job_src), self.code, lane=1)
             head.add('capmi_fill_f32', _p(self.store.grad), 0.0, self.store.size, lane=1)
             if enc.bn_acc_all is not None:          # accumulator rows of capmi_bn_bwd_reduce_spread
                 head.add('capmi_fill_f32', _p(enc.bn_acc_all), 0.0, enc.bn_acc_all.numel(), lane=1)
@@ -204,7 +209,8 @@ class CaptionEngine:
         n_dec = len(bwd)
         if need_enc_bwd:
             enc.plan_backward(bwd, self.W, self.WT, marks)
-        prog = dict(B=B, enc=enc, dec=dec, image=image, image_slot=image_slot, fwd=fwd, fwd_parts=[fwd_enc, fwd_dec], bwd=bwd, graph=None, marks=marks, n_dec=n_dec)
+        prog = dict(B=B, enc=enc, dec=dec, image=image, image_slot=image_slot, fwd=fwd, fwd_parts=[fwd_enc, fwd_dec], bwd=bwd, graph=None, marks=marks, n_dec=n_dec,
+                    forms_in_fwd=any(c[1] == 'capmi_weight_dgrad_form_batched' for c in fwd_enc.calls))
         return prog
 
     def _compile_eval(self, B, beam=1, is_test=False, scored=False):
@@ -378,11 +384,16 @@ class CaptionEngine:
         if self.world > 1:
             torch.distributed.all_reduce(self.store.grad[:self.store.trainable_size], group=self.pg)
 
-    def plan_adam(self, plan, b, e, lrt, lane, grad_scale=1.0, g16=None):
+    def plan_adam(self, plan, b, e, lrt, lane, grad_scale=1.0, g16=None, shadow=False):
         """Adam over flat range [b, e) as a plan entry; lrt: a ctypes.c_float re-read before every run; g16: gradients
-        from this bf16 buffer (same offsets) instead of the f32 gradient buffer."""
+        from this bf16 buffer (same offsets) instead of the f32 gradient buffer; shadow: write the bf16 weight shadow of the
+        range in the same pass (capmi_adam_shadow; returns True when it did, so the caller can drop the range's capmi_cast)."""
         st, cfg = self.store, self.cfg
         clip = float(cfg['gradient_clip']) if cfg.get('gradient_clip') else 0.0
+        if e > b and shadow and g16 is None and self.low is not None and self.code == BF16:
+            plan.add('capmi_adam_shadow', st.flat.data_ptr() + b * 4, st.grad.data_ptr() + b * 4, st.adam_m.data_ptr() + b * 4,
+                     st.adam_v.data_ptr() + b * 4, self.low.data_ptr() + b * 2, e - b, lrt, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, grad_scale, lane=lane)
+            return True
         if e > b and g16 is not None:
             plan.add('capmi_adam_g16', st.flat.data_ptr() + b * 4, g16.data_ptr() + b * 2, st.adam_m.data_ptr() + b * 4,
                      st.adam_v.data_ptr() + b * 4, e - b, lrt, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, grad_scale, lane=lane)
@@ -390,10 +401,14 @@ class CaptionEngine:
             plan.add('capmi_adam', st.flat.data_ptr() + b * 4, st.grad.data_ptr() + b * 4, st.adam_m.data_ptr() + b * 4,
                      st.adam_v.data_ptr() + b * 4, e - b, lrt, ADAM_BETA1, ADAM_BETA2, ADAM_EPS, clip, grad_scale, lane=lane)
 
-    def plan_shadow(self, plan, b, e, lane):
-        """Refresh of the bf16 shadow and of the data-gradient weight forms whose source lies in flat range [b, e)."""
+    def plan_shadow(self, plan, b, e, lane, cast=True, forms=True):
+        """Refresh of the bf16 shadow (cast) and of the data-gradient weight forms (forms) whose source lies in flat range [b, e)."""
         st = self.store
-        if self.low is not None and e > b:
+        if not forms:
+            if cast and self.low is not None and e > b:
+                plan.add('capmi_cast', st.flat.data_ptr() + b * 4, self.low.data_ptr() + b * self.low.element_size(), e - b, self.code, lane=lane)
+            return
+        if cast and self.low is not None and e > b:
             plan.add('capmi_cast', st.flat.data_ptr() + b * 4, self.low.data_ptr() + b * self.low.element_size(), e - b, self.code, lane=lane)
         j0 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= b), len(self.dgrad_job_src))
         j1 = next((i for i, s in enumerate(self.dgrad_job_src) if s >= e), len(self.dgrad_job_src))
@@ -424,11 +439,17 @@ class CaptionEngine:
         cut_idx, cut = cuts[-1] if cuts else (None, total)
         lrt = ctypes.c_float(0.0)
 
+        forms_here = not prog.get('forms_in_fwd', False)      # the data-gradient weight forms are (re)built under the NEXT forward pass
+
+        wrote_shadow = [False]
+
         def optimizer_range(plan, b, e, lane):
-            self.plan_adam(plan, b, e, lrt, lane)
+            wrote_shadow[0] = bool(self.plan_adam(plan, b, e, lrt, lane, shadow=True))
 
         def shadow_range(plan, b, e, lane):
-            self.plan_shadow(plan, b, e, lane)
+            # (always called right behind optimizer_range of the same range: the bf16 shadow came out of capmi_adam_shadow then;
+            # parameters behind the trainable range never change, their shadow dates from refresh_shadows)
+            self.plan_shadow(plan, b, min(e, total) if wrote_shadow[0] else e, lane, cast=not wrote_shadow[0], forms=forms_here)
 
         fused = Plan()
 
