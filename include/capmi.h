@@ -337,9 +337,11 @@ int capmi_bn_finalize_apply(float* ws, int part_rows, int M, int C, const float*
                             float* run_var, float momentum, float eps, float* saved_mean, float* saved_invstd,
                             int update_running, const void* x, const void* res, void* y, int act, int dtype, void* stream);
 /* conv2d -> batch_norm (train mode) of MobileNetV2.py:99-117 WITHOUT the merge + finalize launch between the convolution and
- * the normalisation (bf16).  capmi_igemm_nt_stat is capmi_igemm_nt whose epilogue ADDS the per-column sum v and sum v^2 of its
- * f32 accumulators (f32 atomics) to stat_rows[4][2N], zeroed by the caller once per step; capmi_bn_stat_apply forms
- * mean / invstd / coef_a from the rows in every workgroup's prologue (one-pass variance, clamped at 0), applies
+ * the normalisation (bf16).  capmi_igemm_nt_stat is capmi_igemm_nt whose epilogue ADDS the per-column sums of d = v - shift[n] and
+ * d^2 over its f32 accumulators (f32 atomics) to stat_rows[4][2N], zeroed by the caller once per step; `shift` [N] is any
+ * per-channel estimate of the mean -- the engine hands over the previous step's batch mean (a copy: NOT the saved_mean buffer
+ * of this step), which keeps the one-pass variance free of cancellation.  capmi_bn_stat_apply forms mean = shift + E[d],
+ * var = E[d^2] - E[d]^2 (clamped at 0), invstd and coef_a from the rows in every workgroup's prologue, applies
  * y = act(coef_a * (x - mean) + offset (+ res)) -- capmi_bn_apply's formula; with `mask` also capmi_bn_apply_mask's bits --
  * and its first row block writes saved_mean / saved_invstd / coef_a and updates the running statistics (momentum as
  * capmi_bn_finalize).  Deterministic mode (capmi_set_deterministic) and nothing else switches BOTH entry points to the exact
@@ -348,8 +350,8 @@ int capmi_bn_finalize_apply(float* ws, int part_rows, int M, int C, const float*
  * epilogue (narrow or ragged outputs, f32): use capmi_igemm_nt + capmi_bn_finalize + capmi_bn_apply. */
 int capmi_igemm_nt_stat_supported(const capmi_conv_geom* g, int N, int dtype);
 int capmi_igemm_nt_stat(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
-                        float* parts, float* stat_rows, int dtype, void* stream);
-int capmi_bn_stat_apply(const void* x, float* parts, int part_rows, const float* stat_rows, int M, int C, const float* scale,
+                        float* parts, float* stat_rows, const float* shift, int dtype, void* stream);
+int capmi_bn_stat_apply(const void* x, float* parts, int part_rows, const float* stat_rows, const float* shift, int M, int C, const float* scale,
                         const float* offset, float* run_mean, float* run_var, float momentum, float eps, float* saved_mean,
                         float* saved_invstd, float* coef_a, int update_running, const void* res, void* y, uint8_t* mask, int act,
                         int dtype, void* stream);

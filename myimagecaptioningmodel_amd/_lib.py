@@ -45,8 +45,8 @@ SIGNATURES = {
     'capmi_igemm_nt_bnact': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _i, _p, _i, _p],
     'capmi_igemm_nt_bnfin': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _i, _p],
     'capmi_igemm_nt_bnred': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
-    'capmi_igemm_nt_stat': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _i, _p],
-    'capmi_bn_stat_apply': [_p, _p, _i, _p, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p],
+    'capmi_igemm_nt_stat': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _i, _p],
+    'capmi_bn_stat_apply': [_p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p],
     'capmi_igemm_nt_bnsum': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     'capmi_igemm_nt_group': [ctypes.POINTER(NtCall), _i, _i, _p],
     'capmi_igemm_nt_splitk': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],

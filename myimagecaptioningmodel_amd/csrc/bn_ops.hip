@@ -458,17 +458,18 @@ extern "C" int capmi_bn_apply_mask(const void* x, const float* saved_mean, const
 }
 
 // ------------------------------------------------------------------ finalize inside the apply launch, from accumulator rows
-// capmi_bn_stat_apply: the statistics arrive as four rows of per-channel (sum v, sum v^2) that the convolution's epilogue added
+// capmi_bn_stat_apply: the statistics arrive as four rows of per-channel (sum (v - s), sum (v - s)^2) -- s = `shift`, the batch mean
+// of the previous step -- that the convolution's epilogue added
 // up with f32 atomics (capmi_igemm_nt_stat, igemm.hip EPI 8).  Every workgroup forms mean / invstd / coef_a of ITS channels from
 // the 4 x 2 numbers per channel in its prologue -- the row loads are issued next to the first batch of tensor loads and
 // consumed behind it (as capmi_bn_bwd_apply_spread does: a prologue that waited for them first cost every workgroup one more
 // memory round trip) -- and the first row block also writes saved mean / invstd / coef_a and the running statistics (one
 // writer per channel).  The merge + finalize launch (capmi_bn_finalize: 41 x ~10 us on the forward chain at cfg 2) is gone;
-// unlike capmi_bn_finalize_apply (lesson 30) no workgroup merges parts.  One-pass variance in f32 (var = E[v^2] - mean^2,
-// clamped at 0): relative error ~1e-6 x (1 + mean^2 / var) -- conv outputs have |mean| of the order of their deviation; the
-// f32 engine and deterministic mode keep the exact two-level merge.
+// unlike capmi_bn_finalize_apply (lesson 30) no workgroup merges parts.  One-pass variance in f32 around the shift (var =
+// E[d^2] - E[d]^2, d = v - s, clamped at 0): relative error ~1e-7 x (1 + (mean - s)^2 / var), i.e. that of the exact merge from
+// the second step on; the f32 engine and deterministic mode keep the exact two-level merge.
 template <int ACT, bool RES, bool MASK>
-__global__ __launch_bounds__(256) void bn_stat_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ rows, float inv_m, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void bn_stat_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ rows, const float* __restrict__ shift, float inv_m, const float* __restrict__ scale,
                                                             const float* __restrict__ offset, float* run_mean, float* run_var, float momentum, float eps,
                                                             float* saved_mean, float* saved_invstd, float* coef_a, int update_running,
                                                             const bf16* __restrict__ res, bf16* __restrict__ y, uint8_t* __restrict__ mask, int M, int C, ColLayout L) {
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(256) void bn_stat_apply_kernel(const bf16* __restri
     const int cc = threadIdx.x % L.cpc, rr = threadIdx.x / L.cpc;
     const int chunk = blockIdx.y * L.cpc + cc;
     if (rr >= L.rp || chunk * VEC >= C) return;
-    f32x4 t0[4][2], t1[4][2], scv[2], ofv[2], rmv[2], rvv[2];
+    f32x4 t0[4][2], t1[4][2], scv[2], ofv[2], rmv[2], rvv[2], shv[2];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256) void bn_stat_apply_kernel(const bf16* __restri
     for (int q = 0; q < 2; ++q) {
         scv[q] = *reinterpret_cast<const f32x4*>(scale + chunk * VEC + 4 * q);
         ofv[q] = *reinterpret_cast<const f32x4*>(offset + chunk * VEC + 4 * q);
+        shv[q] = *reinterpret_cast<const f32x4*>(shift + chunk * VEC + 4 * q);
         if (writer && update_running) {
             rmv[q] = *reinterpret_cast<const f32x4*>(run_mean + chunk * VEC + 4 * q);
             rvv[q] = *reinterpret_cast<const f32x4*>(run_var + chunk * VEC + 4 * q);
@@ -517,8 +519,9 @@ __global__ __launch_bounds__(256) void bn_stat_apply_kernel(const bf16* __restri
         float s0 = 0.f, s1 = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s0 += t0[j][v / 4][v % 4]; s1 += t1[j][v / 4][v % 4]; }
-        const float mean = s0 * inv_m;
-        const float var = fmaxf(s1 * inv_m - mean * mean, 0.f);      // biased
+        const float dm = s0 * inv_m;                                 // mean - shift
+        const float mean = shv[v / 4][v % 4] + dm;
+        const float var = fmaxf(s1 * inv_m - dm * dm, 0.f);          // biased
         const float invstd = 1.f / sqrtf(var + eps);
         mu[v] = mean;
         a[v] = scv[v / 4][v % 4] * invstd;
@@ -567,16 +570,17 @@ __global__ __launch_bounds__(256) void bn_stat_apply_kernel(const bf16* __restri
 
 /* capmi_bn_finalize + capmi_bn_apply (or capmi_bn_apply_mask when `mask` is given) behind capmi_igemm_nt_stat, as ONE launch:
  * see capmi.h.  Deterministic mode: the two (three) launches on the exact parts. */
-extern "C" int capmi_bn_stat_apply(const void* x, float* parts, int part_rows, const float* stat_rows, int M, int C, const float* scale,
+extern "C" int capmi_bn_stat_apply(const void* x, float* parts, int part_rows, const float* stat_rows, const float* shift, int M, int C, const float* scale,
                                    const float* offset, float* run_mean, float* run_var, float momentum, float eps, float* saved_mean,
                                    float* saved_invstd, float* coef_a, int update_running, const void* res, void* y, uint8_t* mask, int act,
                                    int dtype, void* stream) {
-    CAPMI_CHECK(x && parts && stat_rows && scale && offset && saved_mean && saved_invstd && coef_a && y, "capmi_bn_stat_apply: null pointer");
+    CAPMI_CHECK(x && parts && stat_rows && shift && scale && offset && saved_mean && saved_invstd && coef_a && y, "capmi_bn_stat_apply: null pointer");
+    CAPMI_CHECK(shift != saved_mean, "capmi_bn_stat_apply: the shift must not be the buffer the new mean is written to (other workgroups still read it)");
     CAPMI_CHECK(!update_running || (run_mean && run_var), "capmi_bn_stat_apply: running stats missing");
     CAPMI_CHECK(dtype == CAPMI_BF16 && C % 8 == 0, "capmi_bn_stat_apply: bf16 tensors with C %% 8 == 0 only (C=%d dtype=%d)", C, dtype);
     CAPMI_CHECK(act == CAPMI_ACT_NONE || act == CAPMI_ACT_RELU || act == CAPMI_ACT_RELU6, "capmi_bn_stat_apply: activation %d (none / relu / relu6)", act);
     CAPMI_CHECK(!mask || act != CAPMI_ACT_NONE, "capmi_bn_stat_apply: the bit mask is for relu / relu6 outputs");
-    CAPMI_CHECK(((uintptr_t)stat_rows | (uintptr_t)scale | (uintptr_t)offset | (uintptr_t)run_mean | (uintptr_t)run_var) % 16 == 0,
+    CAPMI_CHECK(((uintptr_t)stat_rows | (uintptr_t)shift | (uintptr_t)scale | (uintptr_t)offset | (uintptr_t)run_mean | (uintptr_t)run_var) % 16 == 0,
                 "capmi_bn_stat_apply: per-channel vectors must be 16-byte aligned");
     if (capmi_deterministic()) {
         if (capmi_bn_finalize(parts, part_rows, M, C, scale, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, stream)) return 1;
@@ -589,7 +593,7 @@ extern "C" int capmi_bn_stat_apply(const void* x, float* parts, int part_rows, c
     hipStream_t st = (hipStream_t)stream;
     const float inv_m = 1.f / (float)M;
 #define CAPMI_BN_SA(ACT_, RES_, MASK_)                                                                                                          \
-    hipLaunchKernelGGL((bn_stat_apply_kernel<ACT_, RES_, MASK_>), grid, dim3(256), 0, st, (const bf16*)x, stat_rows, inv_m, scale, offset, run_mean, \
+    hipLaunchKernelGGL((bn_stat_apply_kernel<ACT_, RES_, MASK_>), grid, dim3(256), 0, st, (const bf16*)x, stat_rows, shift, inv_m, scale, offset, run_mean, \
                        run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, (const bf16*)res, (bf16*)y, mask, M, C, L)
 #define CAPMI_BN_SA_ACT(ACT_)                                                                              \
     do {                                                                                                   \

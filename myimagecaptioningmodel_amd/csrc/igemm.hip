@@ -117,6 +117,7 @@ struct IGemmArgs {
     // fused batch-norm backward reduction (data-gradient launches): for each of `nred` layers that take
     // this launch's OUTPUT as their dy, per-workgroup column sums of dz and dz*(x-mean)*invstd
     int nred;
+    const float* stat_shift;         // EPI 8: per-column shift s (the layer's batch mean of the previous step): the sums are of (v - s) and (v - s)^2
     int stat_sums;                   // EPI 8 (capmi_igemm_nt_stat): stats = the layer's accumulator rows [4][2N] of (sum v, sum v^2), added with f32 atomics
     int red_mode;                    // 0: the RED template path (capmi_igemm_nt_bnred: per-tile parts, up to two targets); 1 / 2: EPI 7 (capmi_igemm_nt_bnsum), ONE
                                      // target, its sums as f32 atomics into the four accumulator rows rws[0][4][2N] (1) or as per-tile parts rws[0][tile][2][N] (2)
@@ -619,6 +620,25 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+    // EPI 8: this lane's TN shifts, requested before the stores (consumed behind them)
+    float shv8[TN];
+    if constexpr (EPI == 8) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) shv8[j] = 0.f;
+        if (col0 + TN <= a.N) {
+            if constexpr (TN % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < TN / 4; ++q) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(a.stat_shift + col0 + 4 * q);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) shv8[4 * q + e] = t[e];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) shv8[j] = a.stat_shift[col0 + j];
+            }
+        }
+    }
     // output row (scattered for a parity class of a strided data gradient) of the lane's row r of row block i
     auto out_row = [&](int i, int r, bool& valid) -> int64_t {
         const int rl = i * 16 + fg * 4 + r;
@@ -779,18 +799,35 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
         }
     }
     if constexpr (EPI == 8) {
-        // rows past M multiplied the zero page: their accumulators are exactly 0 and add nothing to either sum
+        // Sums of (v - shift) and (v - shift)^2: with the shift near the column's mean (the previous step's batch mean) the
+        // one-pass variance E[d^2] - E[d]^2 loses nothing to cancellation.  Rows past M are left out (their accumulators are 0,
+        // but 0 - shift is not); full row blocks -- all but the last -- take the branch without the per-row test.
         lds_barrier();
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+            const float sh = shv8[j];
             float s1 = 0.f, s2 = 0.f;
+            if (rows_full) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s1 += acc[i][j][r];
-                    s2 += acc[i][j][r] * acc[i][j][r];
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const float d = acc[i][j][r] - sh;
+                        s1 += d;
+                        s2 += d * d;
+                    }
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float d = acc[i][j][r] - sh;
+                        if (i * 16 + fg * 4 + r < wcnt) {
+                            s1 += d;
+                            s2 += d * d;
+                        }
+                    }
+            }
             const float r1 = row4_sum(s1), r2 = row4_sum(s2);
             if (fg == 0) {
                 const int c = wn * WN + TN * fr + j;
@@ -2359,6 +2396,7 @@ static int nt_prepare(IGemmArgs& a, const void* x, const void* w, void* y, const
     a.nred = nred;
     a.red_mode = 0;
     a.stat_sums = 0;
+    a.stat_shift = nullptr;
     for (int q = 0; q < 2; ++q) {
         a.rx[q] = q < nred ? red[q].x : nullptr; a.rmean[q] = q < nred ? red[q].mean : nullptr;
         a.rinv[q] = q < nred ? red[q].invstd : nullptr; a.rws[q] = q < nred ? red[q].ws : nullptr;
@@ -2804,18 +2842,21 @@ extern "C" int capmi_igemm_nt_stat_supported(const capmi_conv_geom* g, int N, in
 }
 /* A training convolution with its batch statistics (IC/model/MobileNetV2.py:99-117: conv2d -> batch_norm, train mode) as
  * capmi_bn_stat_apply consumes them.  Default (bf16): per-column sum v and sum v^2 of the f32 accumulators ADDED (f32 atomics)
- * to stat_rows[4][2N], which the caller zeroes once per step.  Deterministic mode (capmi.h), or a shape without the sums
+ * to stat_rows[4][2N], which the caller zeroes once per step -- the sums are of (v - shift[n]) and its square: any shift is exact in
+ * exact arithmetic, one near the column's mean (the previous step's batch mean) keeps the one-pass variance free of
+ * cancellation in f32.  Deterministic mode (capmi.h), or a shape without the sums
  * epilogue when `parts` is given: the exact (mean, M2) parts of capmi_igemm_nt into `parts` instead -- capmi_bn_stat_apply
  * makes the same choice from the same switch. */
 extern "C" int capmi_igemm_nt_stat(const void* x, const void* w, void* y, const capmi_conv_geom* g, int N, int ldw, int ldy,
-                                   float* parts, float* stat_rows, int dtype, void* stream) {
-    CAPMI_CHECK(parts && stat_rows, "capmi_igemm_nt_stat: null statistics buffer");
+                                   float* parts, float* stat_rows, const float* shift, int dtype, void* stream) {
+    CAPMI_CHECK(parts && stat_rows && shift, "capmi_igemm_nt_stat: null statistics buffer");
     CAPMI_CHECK(capmi_igemm_nt_stat_supported(g, N, dtype), "capmi_igemm_nt_stat: no kernel with the sums epilogue for this shape (capmi_igemm_nt_stat_supported)");
     IGemmArgs a;
     if (nt_prepare(a, x, w, y, g, N, ldw, ldy, nullptr, nullptr, 0, nullptr, 0, parts, 0, 0, 0, 0, nullptr, dtype)) return 1;
     if (!capmi_deterministic()) {
         a.stats = stat_rows;
         a.stat_sums = 1;
+        a.stat_shift = shift;
     }
     return nt_dispatch(a, g, N, a.stats, 0, dtype, (hipStream_t)stream);
 }

@@ -110,6 +110,11 @@ class EncoderRunner:
                 self.shape[op.dst] = ((h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, c)
         z = lambda shape, dt=None: torch.zeros(shape, dtype=dt or self.tdt, device=self.dev)
         self.act, self.grad, self.raw, self.bn = {}, {}, {}, {}
+        # saved batch means of every layer in ONE buffer (views below), and a copy of it taken at the head of every forward plan: the
+        # shift of the one-pass statistics (capmi_igemm_nt_stat / capmi_bn_stat_apply) -- last step's mean, read by kernels that
+        # run while this step's mean is being written
+        nmean = sum((op.cout + 7) // 8 * 8 for op in enc.ops if isinstance(op, arch.ConvBN))
+        self.mean_all, self.shift_all, moff = z((max(nmean, 8),), torch.float32), z((max(nmean, 8),), torch.float32), 0
         self.pool_idx = {}
         max_elems = 0
         for op in enc.ops:
@@ -131,8 +136,9 @@ class EncoderRunner:
                     kk = self.kpad_of(op) if op.src == 0 else op.k * op.k * op.cin
                     part_rows = lib().capmi_igemm_nt_stats_part_rows(M, c, kk, dtype_code)
                 nparts = (M + part_rows - 1) // part_rows
-                self.bn[op.dst] = dict(stats=z((nparts + 64, c, 2), torch.float32), part_rows=part_rows, mean=z((c,), torch.float32),
-                                       invstd=z((c,), torch.float32), a=z((c,), torch.float32))
+                self.bn[op.dst] = dict(stats=z((nparts + 64, c, 2), torch.float32), part_rows=part_rows, mean=self.mean_all[moff:moff + c],
+                                       shift=self.shift_all[moff:moff + c], invstd=z((c,), torch.float32), a=z((c,), torch.float32))
+                moff += (c + 7) // 8 * 8
                 max_elems = max(max_elems, B * h * w * c)
             elif isinstance(op, arch.MaxPool):
                 self.pool_idx[op.dst] = z((B, h, w, c), torch.uint8)
@@ -303,6 +309,7 @@ class EncoderRunner:
         deferred = []               # bn_apply launches moved off the forward chain (operand-path batch norm)
         use_sa = self.stat_apply and not is_test and not self.bnfin
         if use_sa:
+            plan.add('capmi_cast', _p(self.mean_all), _p(self.shift_all), self.mean_all.numel(), 0)      # (dtype code 0 = f32: a plain copy)
             plan.add('capmi_fill_f32', _p(self.fwd_rows_all), 0.0, self.fwd_rows_all.numel())
         for op in self.enc.ops:
             if id(op) in self.skipped:
@@ -346,7 +353,7 @@ class EncoderRunner:
                     plan.add('capmi_s2d_stem', _p(image), _p(self.s2d), B, op.cin, self.S, self.S, op.pad, self.stem_hb, self.stem_wb,
                              self.stem_cs, code)
                     if sa:
-                        plan.add('capmi_igemm_nt_stat', _p(self.s2d), _p(w), _p(raw), sa_geom, c, self.kpad_of(op), c, _p(bn['stats']), sa_rows, code)
+                        plan.add('capmi_igemm_nt_stat', _p(self.s2d), _p(w), _p(raw), sa_geom, c, self.kpad_of(op), c, _p(bn['stats']), sa_rows, _p(bn['shift']), code)
                     else:
                         plan.add('capmi_igemm_nt', _p(self.s2d), _p(w), _p(raw), self._stem_geom(op), c, self.kpad_of(op), c, None, None, 0, None, 0,
                                  None if is_test else _p(bn['stats']), 0, 0, 0, code)
@@ -372,7 +379,7 @@ class EncoderRunner:
                                  BN_MOMENTUM, BN_EPS, _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, code, lane=ln)
                         finalized = True
                     elif sa:
-                        plan.add('capmi_igemm_nt_stat', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, _p(bn['stats']), sa_rows, code, lane=ln)
+                        plan.add('capmi_igemm_nt_stat', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, _p(bn['stats']), sa_rows, _p(bn['shift']), code, lane=ln)
                     else:
                         plan.add('capmi_igemm_nt', _p(self.act[op.src]), _p(w), _p(raw), g, c, K, c, None, None, 0, None, 0,
                                  None if is_test else _p(bn['stats']), 0, 0, 0, code, lane=ln)
@@ -392,7 +399,7 @@ class EncoderRunner:
                 def apply(res, out, act, lane, out_id=None):
                     bits = self.maskbits.get(out_id) if (out_id is not None and not is_test) else None
                     if sa:
-                        plan.add('capmi_bn_stat_apply', _p(raw), _p(bn['stats']), bn['part_rows'], sa_rows, M, c, _p(st.view(op.name + '_bn_scale')), offset,
+                        plan.add('capmi_bn_stat_apply', _p(raw), _p(bn['stats']), bn['part_rows'], sa_rows, _p(bn['shift']), M, c, _p(st.view(op.name + '_bn_scale')), offset,
                                  _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS, _p(bn['mean']),
                                  _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, res, out, _p(bits), act, code, lane=lane)
                     elif bits is not None and not fused_here:

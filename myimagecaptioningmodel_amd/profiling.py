@@ -133,8 +133,8 @@ def describe(name, args):
     if name == 'capmi_bn_stats':
         return 'bn_stats_kernel', 0.0, args[1] * args[2] * es_of(args[4])
     if name == 'capmi_bn_stat_apply':
-        M, C, code = args[4], args[5], args[20]
-        return 'bn_stat_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[16] else 2) + (M * C // 8 if args[18] else 0)
+        M, C, code = args[5], args[6], args[21]
+        return 'bn_stat_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[17] else 2) + (M * C // 8 if args[19] else 0)
     if name == 'capmi_bn_apply_mask':
         M, C, code = args[7], args[8], args[10]
         return 'bn_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[4] else 2) + M * C // 8

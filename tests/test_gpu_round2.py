@@ -371,7 +371,7 @@ def test_relu_masks_as_bits_in_the_engine_are_bit_identical(monkeypatch, determi
         enc = prog['enc']
         out[mode] = dict(loss=loss, grads=eng.export_reference_grads(), g={k: v.clone() for k, v in enc.grad.items()},
                          act={k: v.clone() for k, v in enc.act.items()}, bits={k: v.clone() for k, v in enc.maskbits.items()},
-                         calls=['capmi_bn_apply_mask' if (c[1] == 'capmi_bn_stat_apply' and c[2][18]) else c[1]      # (capmi_bn_stat_apply with a mask
+                         calls=['capmi_bn_apply_mask' if (c[1] == 'capmi_bn_stat_apply' and c[2][19]) else c[1]      # (capmi_bn_stat_apply with a mask
                                 for c in prog['fwd'].calls if c[0] is not None])                                      #  pointer = finalize + capmi_bn_apply_mask)
     a, b = out['0'], out['1']
     assert len(a['bits']) == 0 and len(b['bits']) >= 40 and b['calls'].count('capmi_bn_apply_mask') == len(b['bits'])
@@ -406,7 +406,7 @@ def test_operand_path_batch_norm_in_the_engine_is_bit_identical(level, monkeypat
         enc = prog['enc']
         out[mode] = dict(loss=loss, logits=prog['dec'].logits.clone(), raw={k: v.clone() for k, v in enc.raw.items()},
                          act={k: v.clone() for k, v in enc.act.items()}, grads=eng.export_reference_grads(), n_fused=len(enc.inbn),
-                         calls=['capmi_bn_apply_mask' if (c[1] == 'capmi_bn_stat_apply' and c[2][18]) else c[1]      # (capmi_bn_stat_apply with a mask
+                         calls=['capmi_bn_apply_mask' if (c[1] == 'capmi_bn_stat_apply' and c[2][19]) else c[1]      # (capmi_bn_stat_apply with a mask
                                 for c in prog['fwd'].calls if c[0] is not None])                                      #  pointer = finalize + capmi_bn_apply_mask)
     a, b = out[0], out[level]
     assert a['n_fused'] == 0 and b['n_fused'] >= (10 if level == 1 else 16), b['n_fused']

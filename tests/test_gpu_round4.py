@@ -150,17 +150,23 @@ def test_conv_statistics_as_accumulator_rows_and_finalize_in_the_apply_launch(B,
     acode = _lib.ACT_CODES[act]
     p = lambda t: None if t is None else t.data_ptr()
 
-    def run(fused):
+    # any shift is exact in exact arithmetic: zero (a first step), and a value near the true mean (every later step)
+    xf = x.float().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    wf = w.float().permute(0, 3, 1, 2)
+    true_mean = torch.nn.functional.conv2d(xf, wf, padding=pad).mean(dim=(0, 2, 3)).cpu().numpy()
+
+    def run(fused, shift_np=np.zeros(Co, np.float32)):
         raw = torch.zeros((M, Co), dtype=torch.bfloat16, device=dev)
         y = torch.zeros((M, Co), dtype=torch.bfloat16, device=dev)
         parts = torch.zeros(((nparts + 64) * Co * 2,), dtype=torch.float32, device=dev)
         rows = torch.zeros((4, 2 * Co), dtype=torch.float32, device=dev)
+        shift = torch.tensor(shift_np, dtype=torch.float32, device=dev)
         mean, inv, ca = (torch.zeros(Co, dtype=torch.float32, device=dev) for _ in range(3))
         rm, rv = torch.full((Co,), 0.25, dtype=torch.float32, device=dev), torch.full((Co,), 2.0, dtype=torch.float32, device=dev)
         bits = torch.zeros((M * Co // 8,), dtype=torch.uint8, device=dev) if act else None
         if fused:
-            _lib.call('capmi_igemm_nt_stat', p(x), p(w), p(raw), g, Co, K, Co, p(parts), p(rows), _lib.BF16, st)
-            _lib.call('capmi_bn_stat_apply', p(raw), p(parts), pr, p(rows), M, Co, p(scale), p(offset), p(rm), p(rv), 0.9, 1e-5, p(mean), p(inv), p(ca), 1,
+            _lib.call('capmi_igemm_nt_stat', p(x), p(w), p(raw), g, Co, K, Co, p(parts), p(rows), p(shift), _lib.BF16, st)
+            _lib.call('capmi_bn_stat_apply', p(raw), p(parts), pr, p(rows), p(shift), M, Co, p(scale), p(offset), p(rm), p(rv), 0.9, 1e-5, p(mean), p(inv), p(ca), 1,
                       p(resid), p(y), p(bits), acode, _lib.BF16, st)
         else:
             _lib.call('capmi_igemm_nt', p(x), p(w), p(raw), g, Co, K, Co, None, None, 0, None, 0, p(parts), 0, 0, 0, _lib.BF16, st)
@@ -176,6 +182,10 @@ def test_conv_statistics_as_accumulator_rows_and_finalize_in_the_apply_launch(B,
     for i, name in ((2, 'mean'), (3, 'invstd'), (4, 'coef_a'), (5, 'running mean'), (6, 'running variance')):
         err = float((a[i] - b[i]).abs().max()) / max(1e-6, float(b[i].abs().max()))
         assert err <= 2e-5, (name, err)
+    c = run(True, (true_mean * (1 + 0.01 * rng.standard_normal(Co))).astype(np.float32))      # last step's mean as the shift
+    for i, name in ((2, 'mean'), (3, 'invstd'), (4, 'coef_a'), (5, 'running mean'), (6, 'running variance')):
+        err = float((c[i] - b[i]).abs().max()) / max(1e-6, float(b[i].abs().max()))
+        assert err <= 3e-6, (name, err, 'shifted')
     ya, yb = a[1].float(), b[1].float()
     ulp = torch.clamp(yb.abs(), min=2.0 ** -6) * 2.0 ** -7
     assert bool(((ya - yb).abs() <= ulp).all()) and float((ya != yb).float().mean()) < 0.02
