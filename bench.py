@@ -269,6 +269,9 @@ def extras(eng, cfg, B, image_d, cap_d, dev, steps=10):
             res[key + '_images_per_sec'] = rate(e, steps if key != 'f32_slots' else max(3, steps // 2))
         del e
         torch.cuda.empty_cache()
+    # the reference-precision engine against ITS roof: exact-f32 MFMA (v_mfma_f32_16x16x4_f32), 157.3 TFLOP/s dense
+    from myimagecaptioningmodel_amd import profiling
+    res['f32_slots_model_mfma_frac'] = round(res['f32_slots_images_per_sec'] * FLOPS_PER_IMAGE[1] / (profiling.PEAK_MFMA_TFLOPS['f32'] * 1e12), 4)
     res['first_step_loss'] = {k: round(v, 5) for k, v in first.items()}
     res['loss_gap_bf16_vs_f32_engine'] = round(abs(first['bf16_slots'] - first['f32_slots']), 5)
     res['note'] = ('singleton = the reference graph as written (alpha == 1); f32 = reference precision (exact-f32 MFMA kernels); losses and the '
