@@ -63,6 +63,25 @@ def dev_evaluation(engine, dev_batches, metric, log_path=None, index_word=None):
     return eval_score
 
 
+def exchange_failure(pg, device, err):
+    """Data parallel: every rank learns whether ANY rank failed in this step (a sticky grid-barrier time-out, a NaN loss, a metric
+    exception) before the next collective -- a rank that raised alone would leave the others waiting in the next bucket all-reduce
+    for ever.  One 4-byte all-reduce per step; every rank then raises (the failing one its own error), which also tears the
+    process group down.  pg None: single process, `err` is simply raised."""
+    if pg is None:
+        if err is not None:
+            raise err
+        return
+    import torch
+    import torch.distributed as dist
+    flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float32, device=device if dist.get_backend(pg) == 'nccl' else 'cpu')
+    dist.all_reduce(flag, group=pg)
+    if err is not None:
+        raise err
+    if float(flag.item()) > 0:
+        raise RuntimeError('capmi train loop: another rank failed in this step (rank %d stops with it)' % dist.get_rank(pg))
+
+
 def _rank_world(engine):
     pg = getattr(engine, 'pg', None)
     if pg is None:
@@ -105,22 +124,8 @@ def train(engine, batches_per_epoch, max_epoch, checkpoint_path, log_path, log_e
     step_fn = trainer.train_step if trainer is not None else engine.train_step
 
     def all_ok(err):
-        """Data parallel: every rank learns whether ANY rank failed in this step (a sticky grid-barrier time-out, a NaN loss, a
-        reader or metric exception) before the next collective -- a rank that raised alone would leave the others waiting in
-        the next bucket all-reduce for ever.  One 4-byte all-reduce per step on the host-visible path; every rank then raises
-        (the failing one its own error), which also tears the process group down."""
-        if dist is None or world <= 1:
-            if err is not None:
-                raise err
-            return
-        import torch
-        flag = torch.tensor([0.0 if err is None else 1.0], dtype=torch.float32,
-                            device=engine.device if dist.get_backend(engine.pg) == 'nccl' else 'cpu')
-        dist.all_reduce(flag, group=engine.pg)
-        if err is not None:
-            raise err
-        if float(flag.item()) > 0:
-            raise RuntimeError('capmi train loop: another rank failed in this step (rank %d stops with it)' % rank)
+        exchange_failure(engine.pg if dist is not None and world > 1 else None, engine.device, err)
+
     for epoch in range(conf['epoch'], max_epoch + 1):
         conf['epoch'] = epoch                                   # written at the START of the epoch (train.py:134)
         if lead:

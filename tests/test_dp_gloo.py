@@ -110,3 +110,41 @@ def test_grad_buckets_cut_only_at_segment_boundaries():
     # the last bucket (its all-reduce is exposed) shrinks to the smallest tail of >= tail_bytes the cuts allow
     t = dp.GradBuckets(1000, [100, 250, 400, 900, 950, 990], bucket_bytes=4 * 300, elem_bytes=4, tail_bytes=4 * 40)
     assert t.ranges == [(0, 400), (400, 900), (900, 950), (950, 1000)]
+
+
+def _failure_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from myimagecaptioningmodel_amd import dp, train_loop
+    pg, r, w, _ = dp.init_process_group_from_env(backend='gloo')
+    seen = []
+    for step in range(3):
+        err = AssertionError('Epoch:1 Step:%d Loss为Nan' % (step + 1)) if (rank == 1 and step == 1) else None     # rank 1 fails alone in step 2
+        try:
+            train_loop.exchange_failure(pg, 'cpu', err)
+            seen.append('ok')
+        except AssertionError as e:
+            seen.append('own:' + str(e))
+            break
+        except RuntimeError as e:
+            seen.append('other:' + str(e))
+            break
+    out.put((rank, seen))
+    dist.destroy_process_group()
+
+
+def test_a_rank_that_fails_alone_stops_every_rank_before_the_next_collective():
+    """train_loop.exchange_failure (the per-step flag of the data-parallel loop, train.py:139-141 under ParallelExecutor): rank 1
+    raises its NaN assertion in step 2; rank 0 -- whose own step was fine -- raises too instead of entering the next all-reduce."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failure_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    assert res[1] == ['ok', 'own:Epoch:1 Step:2 Loss为Nan']
+    assert res[0][0] == 'ok' and res[0][1].startswith('other:') and 'another rank failed' in res[0][1] and len(res[0]) == 2
