@@ -280,7 +280,7 @@ def extras(eng, cfg, B, image_d, cap_d, dev, steps=10):
     return res
 
 
-def decode_measure(B, beam, steps, warmup, use_graph=True):
+def decode_measure(B, beam, steps, warmup, use_graph=True, pipelined=0):
     """BASELINE configs[4]: the infer.py path (/root/reference/ImageCaptioning/infer.py:26-36 runs the saved GREEDY graph on
     one image; beam search is this build's extension) at batch B, 224x224, ResNet-50 + 512-d decoder, bf16, `is_test`
     batch norm as in the exported inference model.  One step = one batch decoded (encoder + Ti = 20 decoder steps +
@@ -306,20 +306,37 @@ def decode_measure(B, beam, steps, warmup, use_graph=True):
     ids = ids.cpu().numpy()
     assert ids.shape == (B, cfg['infer_max_length']) and ((ids >= 0) & (ids < cfg['vocab'])).all()
     lat.sort()
+    res = dict(captions_per_sec=round(B * steps / dt, 1), ms_per_batch=round(dt / steps * 1e3, 3),
+               p50_latency_ms=round(lat[len(lat) // 2] * 1e3, 3), p90_latency_ms=round(lat[int(len(lat) * 0.9)] * 1e3, 3),
+               batch=B, beam=beam, steps=steps)
+    if pipelined:
+        # the serving form of the same path: `pipelined` batches in flight on as many HIP streams (CaptionEngine.decode_pipelined);
+        # a batch's latency is then no longer the reciprocal of the rate, so both are reported
+        n = max(64, 4 * steps)          # long enough that filling and draining the pipeline (one batch time each) is a few per cent
+        feeds = [image_d] * n
+        one = eng.decode(image_d, beam=beam, is_test=True).clone()
+        for _ in range(2):
+            outs = eng.decode_pipelined(feeds[:8], beam=beam, depth=pipelined + 1, decoders=pipelined)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        outs = eng.decode_pipelined(feeds, beam=beam, depth=pipelined + 1, decoders=pipelined)
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - t0
+        assert all(bool((o == one).all()) for o in outs), 'pipelined decode changed the ids'
+        res['pipelined'] = dict(decoders_in_flight=pipelined, program_copies=pipelined + 1, batches=n, captions_per_sec=round(B * n / dtp, 1), ms_per_batch=round(dtp / n * 1e3, 3),
+                                ids_equal_to_one_at_a_time=True)
     del eng
     torch.cuda.empty_cache()
-    return dict(captions_per_sec=round(B * steps / dt, 1), ms_per_batch=round(dt / steps * 1e3, 3),
-                p50_latency_ms=round(lat[len(lat) // 2] * 1e3, 3), p90_latency_ms=round(lat[int(len(lat) * 0.9)] * 1e3, 3),
-                batch=B, beam=beam, steps=steps)
+    return res
 
 
 def decode_bench(args):
     """`--decode`: BASELINE configs[4] as its own JSON line."""
     B, beam = args.batch or 128, args.beam
-    m = decode_measure(B, beam, args.steps, args.warmup, use_graph=not args.no_graph)
+    m = decode_measure(B, beam, args.steps, args.warmup, use_graph=not args.no_graph, pipelined=0 if args.no_graph else args.in_flight)
     out = {'metric': 'decode captions/sec (224x224, beam=%d, batch %d)' % (beam, B), 'value': m['captions_per_sec'], 'unit': 'captions/sec',
            'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': m['ms_per_batch'],
-           'p50_latency_ms': m['p50_latency_ms'], 'p90_latency_ms': m['p90_latency_ms'],
+           'p50_latency_ms': m['p50_latency_ms'], 'p90_latency_ms': m['p90_latency_ms'], 'pipelined': m.get('pipelined'),
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
            'config': {'workload': 'BASELINE configs[4]: infer.py path, ResNet-50 (build-defined) + 512-d decoder, vocab 10000, 224x224, '
                                   'Ti 20, beam %d (build-defined; beam 1 = the reference greedy loop), is_test batch norm, random-init weights' % beam,
@@ -367,6 +384,7 @@ def main():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: the BASELINE config: 64 train, 128 decode)')
     ap.add_argument('--decode', action='store_true', help='BASELINE configs[4]: beam-search decode captions/sec + p50 latency (extra mode)')
     ap.add_argument('--beam', type=int, default=5)
+    ap.add_argument('--in-flight', type=int, default=3, help='--decode: also time the serving form (CaptionEngine.decode_pipelined) with this many decoders in flight beside an encoder (0: skip)')
     ap.add_argument('--config', type=int, default=1, choices=[1, 3], help='1 (default): the bench workload, BASELINE configs[1]; 3: BASELINE configs[3] '
                     '(ResNet-101 + 2-layer 1024-d LSTM, 384x384, L = 30, V = 20 000) as its own JSON line -- an extra mode like --decode')
     ap.add_argument('--no-extras', action='store_true', help='skip the extra lines (singleton attention, f32, loss gap)')
@@ -542,7 +560,7 @@ def main():
         progress('extra: config3 (ResNet-101 + 2-layer 1024-d LSTM, 384x384)')
         out['extra']['config3'] = config3_measure(dev)
         progress('extra: decode_beam5 (batch 128)')
-        out['extra']['decode_beam5'] = decode_measure(128, 5, 10, 2)
+        out['extra']['decode_beam5'] = decode_measure(128, 5, 10, 2, pipelined=3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.config == 3:
             out['cpu_baseline'] = cpu_baseline(cfg, budget_s=40.0, probe_batch=1, max_batch=4,

@@ -222,10 +222,10 @@ class CaptionEngine:
         dec = DecoderRunner(self.store, B, K, max(1, beam), self.code, self.tdt, self.slots, False)
         image = torch.zeros((B, 3, S, S), dtype=torch.float32, device=self.device)
         out = torch.zeros((B, Ti), dtype=torch.float32, device=self.device)
-        plan = Plan()
+        plan_enc, plan = Plan(), Plan()             # two plans: decode_pipelined runs them on two streams
         # in-training eval graph: batch statistics AND running-stat update (quirk Q3); is_test: the exported
         # inference model (infer.py) -- running statistics, nothing updated
-        enc.plan_forward(plan, image, self.W, update_running=not is_test, is_test=is_test)
+        enc.plan_forward(plan_enc, image, self.W, update_running=not is_test, is_test=is_test)
         if beam <= 1 and not scored:
             es = dec.Hbuf.element_size()
             for hb, cb in zip(dec.Hbufs, dec.Cbufs):                                 # zero state of every LSTM layer (:63)
@@ -234,7 +234,7 @@ class CaptionEngine:
             dec.plan_greedy(plan, enc.out_tensor(), self.W, out, Ti)
         else:
             dec.plan_beam(plan, enc.out_tensor(), self.W, out, Ti, max(1, beam))
-        return dict(B=B, enc=enc, dec=dec, image=image, out=out, plan=plan, graph=None, beam=beam)
+        return dict(B=B, enc=enc, dec=dec, image=image, out=out, plan_enc=plan_enc, plan_dec=plan, graph=None, beam=beam, scored=scored)
 
     def _run_captured(self, prog, key, plans):
         """Replays `plans` from a hipGraph captured on first use (static shapes and pointers).
@@ -508,32 +508,102 @@ class CaptionEngine:
         self.refresh_shadows()
         return loss, lr
 
+    def _eval_prog(self, B, beam, is_test, scored=False, slot=0):
+        key = (B, int(beam), bool(is_test)) + (('scored',) if scored else ()) + (('slot', int(slot)) if slot else ())
+        prog = self._eval.get(key)
+        if prog is None:
+            prog = self._eval[key] = self._compile_eval(B, int(beam), bool(is_test), scored)
+        return prog
+
+    def _eval_feed(self, prog, image):
+        img = self._as_tensor(image, torch.float32, self.device)
+        if tuple(img.shape) != tuple(prog['image'].shape):
+            raise ValueError('image feed must be %s, got %s' % (tuple(prog['image'].shape), tuple(img.shape)))
+        prog['image'].copy_(img)
+
+    def _eval_init(self, prog):
+        dec, B, beam = prog['dec'], prog['B'], prog['beam']
+        dec.refresh_stacked(self.W, (getattr(self, 'shadow_version', 0), self.step_count, id(self.store.flat)))
+        dec.ids[:max(1, beam) * B].fill_(self.cfg['start_idx'])                   # :56-58
+        if beam > 1 or prog['scored']:
+            dec.beam_score[0].fill_(-1e30)
+            dec.beam_score[0][0].zero_()
+
     def decode(self, image, beam=1, is_test=False, scored=False):
         """Decode of the eval graph: float32 ids [B, infer_max_length] (quirk Q2).  beam = 1: the reference's greedy
         loop (:119-123); beam > 1: beam search (build-defined, see DecoderRunner.plan_beam), best hypothesis
         returned.  is_test: batch norm on the running statistics, as in the exported inference model (infer.py);
         the default is the in-training eval graph (batch statistics, running stats updated: quirk Q3).  scored: run a
         beam of one through the beam-search plan too, so that decode_scores() has the greedy caption's log-probability."""
-        B = int(image.shape[0])
         scored = bool(scored) and beam <= 1
-        key = (B, int(beam), bool(is_test)) + (('scored',) if scored else ())
-        prog = self._eval.get(key)
-        if prog is None:
-            prog = self._eval[key] = self._compile_eval(B, int(beam), bool(is_test), scored)
+        prog = self._eval_prog(int(image.shape[0]), beam, is_test, scored)
         if self.shadows_dirty:
             self.refresh_shadows()
-        img = self._as_tensor(image, torch.float32, self.device)
-        if tuple(img.shape) != tuple(prog['image'].shape):
-            raise ValueError('image feed must be %s, got %s' % (tuple(prog['image'].shape), tuple(img.shape)))
-        prog['image'].copy_(img)
-        dec = prog['dec']
-        dec.refresh_stacked(self.W, (getattr(self, 'shadow_version', 0), self.step_count, id(self.store.flat)))
-        dec.ids[:max(1, beam) * B].fill_(self.cfg['start_idx'])                   # :56-58
-        if beam > 1 or scored:
-            dec.beam_score[0].fill_(-1e30)
-            dec.beam_score[0][0].zero_()
-        self._run_captured(prog, 'graph', [prog['plan']])
+        self._eval_feed(prog, image)
+        self._eval_init(prog)
+        self._run_captured(prog, 'graph', [prog['plan_enc'], prog['plan_dec']])
         return prog['out']
+
+    def decode_pipelined(self, batches, beam=1, depth=4, decoders=3, graph=False):
+        """The infer.py path (`is_test` batch norm) over a sequence of image batches as a two-stage pipeline: the encoder of
+        a later batch -- long kernels that fill the chip -- runs on one HIP stream under the decoder steps of `decoders`
+        earlier batches on streams of their own (higher priority: 11 short dependent launches per word on a few dozen
+        workgroups each; beside an encoder each of them waits for room, which is why more than one decoder is in flight).
+        `depth` copies of the program (activation buffers, decoder state) take the batches in turn; the encoder of batch
+        i + depth waits for the decoder of batch i.  Same ids as decode(): the kernels and their order within a batch are
+        the same, only their neighbours on the chip differ.  Returns one [B, infer_max_length] float32 tensor per batch
+        (copies: a slot's output buffer is reused `depth` batches later); the caller's stream has waited for all of them on
+        return.  graph: walk the launch plans (default: one foreign call per stage, the host stays ahead) or replay captured
+        graphs (hipGraph launches behind cross-stream waits run late on this runtime: slower whenever fewer than three
+        decoders hide it).  is_test only: the in-training eval graph updates the running statistics (quirk Q3), which orders
+        its batches.  Measured at BASELINE configs[4] (batch 128, beam 5, 64 batches; tools/decode_pipe.py): one batch at a
+        time 5.8 ms; plan walks: 3 copies / 2 decoders 4.46-4.50, 4 / 3 4.30-4.32 (29 700 captions/s), 6 / 3 4.32-4.36; graph
+        replay: 3 / 2 5.9, 3 / 3 5.2, 4 / 3 4.42.  A fourth decoder stream is a fifth stream on four hardware queues and
+        shares one with the encoder (6.6 ms) -- hence at most three."""
+        decoders = min(3, max(1, int(decoders)))
+        depth = max(decoders, int(depth))
+        cur = torch.cuda.current_stream(self.device)
+        if self.shadows_dirty:
+            self.refresh_shadows()
+        if getattr(self, '_pipe_streams', None) is None:
+            self._pipe_streams = [torch.cuda.Stream(device=self.device)]
+        prio = int(os.environ.get('CAPMI_PIPE_PRIORITY', '-1'))
+        while len(self._pipe_streams) < 1 + decoders:
+            self._pipe_streams.append(torch.cuda.Stream(device=self.device, priority=prio))
+        E, Ds = self._pipe_streams[0], self._pipe_streams[1:1 + decoders]
+        for st in [E] + Ds:
+            st.wait_stream(cur)
+        use_graph = bool(graph) and self.use_graph
+
+        def run(prog, key, plan, st):
+            if use_graph:
+                self._run_captured(prog, key, [plan])
+            else:
+                plan.run(st.cuda_stream)
+        dec_done = [None] * depth
+        outs = []
+        for i, image in enumerate(batches):
+            prog = self._eval_prog(int(image.shape[0]), beam, True, slot=1 + i % depth)
+            D = Ds[i % decoders]
+            with torch.cuda.stream(E):
+                if dec_done[i % depth] is not None:
+                    E.wait_event(dec_done[i % depth])
+                self._eval_feed(prog, image)
+                run(prog, 'graph_enc', prog['plan_enc'], E)
+                enc_done = torch.cuda.Event()
+                enc_done.record(E)
+            if torch.is_tensor(image) and image.is_cuda:
+                image.record_stream(E)
+            with torch.cuda.stream(D):
+                D.wait_event(enc_done)
+                self._eval_init(prog)
+                run(prog, 'graph_dec', prog['plan_dec'], D)
+                outs.append(prog['out'].clone())
+                dec_done[i % depth] = torch.cuda.Event()
+                dec_done[i % depth].record(D)
+        for st in [E] + Ds:
+            cur.wait_stream(st)
+        return outs
 
     def check_sync(self):
         """Raises CapmiError if a grid barrier inside a persistent kernel gave up waiting in any step since the last call

@@ -226,3 +226,31 @@ def test_forward_statistics_path_in_the_engine(monkeypatch):
             # what 50 batch norms over 256-16k samples make of those differences at random initialisation
             tol = 1e-4 if n.startswith(('res_conv1', 'res2_1_branch2a', 'res2_1_branch1')) else 5e-2
             assert np.abs(p1[n] - p0[n]).max() <= tol * max(1.0, np.abs(p0[n]).max()), n
+
+
+def test_pipelined_decode_returns_the_ids_of_one_batch_at_a_time():
+    """CaptionEngine.decode_pipelined (encoders on one stream, the decoders of up to three earlier batches on streams of
+    their own, each batch on its own copy of the program) against decode() batch by batch: same kernels in the same order
+    within a batch, so the ids are equal -- from captured graphs and from plan walks."""
+    from myimagecaptioningmodel_amd import default_cfg
+    from myimagecaptioningmodel_amd.model import CaptionEngine
+    B, S, L = 8, 64, 8
+    cfg = default_cfg(encoder='resnet50', image_size=S, hidden=64, embed=32, vocab=200, sentence_length=L, infer_max_length=L,
+                      attention='slots', dtype='bf16', batch_size=B)
+    eng = CaptionEngine(cfg, device='cuda:0', use_graph=True)
+    rng = np.random.RandomState(5)
+    feeds = [torch.as_tensor(rng.uniform(0, 1, (B, 3, S, S)).astype(np.float32)).to('cuda:0') for _ in range(9)]
+    for beam in (1, 3):
+        want = [eng.decode(f, beam=beam, is_test=True).clone() for f in feeds]
+        for depth, decoders, graph in ((1, 1, True), (2, 1, True), (3, 2, False), (4, 3, True), (4, 3, False)):
+            got = eng.decode_pipelined(feeds, beam=beam, depth=depth, decoders=decoders, graph=graph)
+            torch.cuda.synchronize()
+            assert len(got) == len(feeds)
+            for g, w in zip(got, want):
+                assert torch.equal(g, w)
+            got = eng.decode_pipelined(feeds[::-1], beam=beam, depth=depth, decoders=decoders, graph=graph)   # other feeds per copy
+            torch.cuda.synchronize()
+            for g, w in zip(got, want[::-1]):
+                assert torch.equal(g, w)
+    with pytest.raises(ValueError):
+        eng.decode_pipelined([feeds[0][:, :, :32]], beam=1)          # a feed of another image size is refused, as in decode()
