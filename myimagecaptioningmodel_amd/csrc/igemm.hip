@@ -620,24 +620,11 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // EPI 8: this lane's TN shifts, requested before the stores (consumed behind them)
-    float shv8[TN];
+    // EPI 8: the shift of column n0 + tid, requested before the stores and consumed at the very end of the epilogue (loads and
+    // stores share vmcnt: by then the stores have long been acknowledged -- a use right behind them waited for every one)
+    float sh8 = 0.f;
     if constexpr (EPI == 8) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) shv8[j] = 0.f;
-        if (col0 + TN <= a.N) {
-            if constexpr (TN % 4 == 0) {
-#pragma unroll
-                for (int q = 0; q < TN / 4; ++q) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(a.stat_shift + col0 + 4 * q);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) shv8[4 * q + e] = t[e];
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < TN; ++j) shv8[j] = a.stat_shift[col0 + j];
-            }
-        }
+        if (tid < BN && n0 + tid < a.N) sh8 = a.stat_shift[n0 + tid];
     }
     // output row (scattered for a parity class of a strided data gradient) of the lane's row r of row block i
     auto out_row = [&](int i, int r, bool& valid) -> int64_t {
@@ -799,36 +786,26 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
         }
     }
     if constexpr (EPI == 8) {
-        // Sums of (v - shift) and (v - shift)^2: with the shift near the column's mean (the previous step's batch mean) the
-        // one-pass variance E[d^2] - E[d]^2 loses nothing to cancellation.  Rows past M are left out (their accumulators are 0,
-        // but 0 - shift is not); full row blocks -- all but the last -- take the branch without the per-row test.
+        // Per-tile sums of v and v^2 over the tile's BM rows -- packed f32 (v_pk_add_f32 / v_pk_fma_f32: two rows per instruction,
+        // 10 VALU per column where the shifted, per-row-tested form took 24; rows past M hold zeros and add nothing) -- folded over
+        // the wave and the WMW waves, and only THEN shifted: with n valid rows, sum (v - s) = t1 - n s and sum (v - s)^2 =
+        // t2 - s (t1 + (t1 - n s)).  What the atomics add up over the M / BM tiles are the shifted sums, so with the shift near the
+        // column's mean (the previous step's batch mean) the one-pass variance E[d^2] - E[d]^2 loses nothing to cancellation over
+        // the tensor; inside a tile (128 rows, a register tree) the unshifted sums are good to ~1e-7 of t2.
+        typedef __attribute__((ext_vector_type(2))) float f32x2;
         lds_barrier();
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float sh = shv8[j];
-            float s1 = 0.f, s2 = 0.f;
-            if (rows_full) {
+            f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float d = acc[i][j][r] - sh;
-                        s1 += d;
-                        s2 += d * d;
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float d = acc[i][j][r] - sh;
-                        if (i * 16 + fg * 4 + r < wcnt) {
-                            s1 += d;
-                            s2 += d * d;
-                        }
-                    }
+            for (int i = 0; i < TM; ++i) {
+                const f32x2 lo = {acc[i][j][0], acc[i][j][1]}, hi = {acc[i][j][2], acc[i][j][3]};
+                p1 += lo;
+                p2 = __builtin_elementwise_fma(lo, lo, p2);
+                p1 += hi;
+                p2 = __builtin_elementwise_fma(hi, hi, p2);
             }
-            const float r1 = row4_sum(s1), r2 = row4_sum(s2);
+            const float r1 = row4_sum(p1[0] + p1[1]), r2 = row4_sum(p2[0] + p2[1]);
             if (fg == 0) {
                 const int c = wn * WN + TN * fr + j;
                 sred[(wm * BN + c) * 2 + 0] = r1;
@@ -840,9 +817,12 @@ __device__ __forceinline__ void nt_epilogue(const IGemmArgs& a, f32x4 (&acc)[BM 
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WMW; ++w) { t1 += sred[(w * BN + tid) * 2]; t2 += sred[(w * BN + tid) * 2 + 1]; }
+            const float nrows = (float)min(BM, a.M - m0);
+            const float u1 = __builtin_fmaf(-nrows, sh8, t1);               // sum (v - s)
+            const float u2 = __builtin_fmaf(-sh8, t1 + u1, t2);             // sum (v - s)^2
             float* row = a.stats + (int64_t)((m0 / BM) & 3) * 2 * a.N + n0 + tid;
-            __hip_atomic_fetch_add(row, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(row + a.N, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(row, u1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(row + a.N, u2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (EPI <= 1 && a.stats) {      // (EPI 2 / 3 / 4 never carry statistics)
