@@ -973,11 +973,17 @@ __global__ __launch_bounds__(256) void beam_topk_kernel(const float* __restrict_
 template <int NV>
 __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* __restrict__ logits, int V, int ld, int beam, float* cand_val,
                                                             int* cand_idx, float* lse) {
-    __shared__ float scratch[16];
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    __shared__ int s_pick;
-    const int m = blockIdx.x, tid = threadIdx.x;
+    // ONE barrier per selection round (the first form took nineteen for beam 5: two each for the max and the sum, three per
+    // round): every lane keeps the best of ITS values; a round folds the lane bests over the wave with shuffles, the four wave
+    // winners meet in LDS (two buffers, alternating: a round's writes cannot overtake the reads of the round before last, which
+    // all happened before the barrier in between), EVERY thread picks the winner from the four -- no thread-0 section, no
+    // broadcast -- and only the lane that held it rescans its values.  The row maximum is round 0's winner; the sum of
+    // exponentials rides in round 1's exchange (its own exchange when beam == 1).  Same results bit for bit: same order (value
+    // desc, index asc), same per-lane / per-wave / wave-order summation as block_sum.
+    __shared__ float sv[2][4];
+    __shared__ int si[2][4];
+    __shared__ float ssum[16];
+    const int m = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
     const float* row = logits + (int64_t)m * ld;
     f32x4 r[NV];
 #pragma unroll
@@ -985,25 +991,16 @@ __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* __restr
         const int i = (j * 256 + tid) * 4;
         r[j] = i < V ? *reinterpret_cast<const f32x4*>(row + i) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
-    float mx = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NV; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 4; ++e)
             if ((j * 256 + tid) * 4 + e >= V) r[j][e] = -INFINITY;      // columns V .. ld-1 of the padded row
-            mx = fmaxf(mx, r[j][e]);
-        }
-    mx = block_max(mx, scratch);
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) sum += expf(r[j][e] - mx);
-    sum = block_sum(sum, scratch);
-    if (tid == 0) lse[m] = mx + logf(sum);
-    for (int q = 0; q < beam; ++q) {
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
+    float best;
+    int bi;
+    auto lane_best = [&]() {
+        best = -INFINITY;
+        bi = 0x7fffffff;
 #pragma unroll
         for (int j = 0; j < NV; ++j)
 #pragma unroll
@@ -1011,32 +1008,61 @@ __global__ __launch_bounds__(256) void beam_topk_reg_kernel(const float* __restr
                 const float f = r[j][e];
                 if (f > best) { best = f; bi = (j * 256 + tid) * 4 + e; }
             }
+    };
+    lane_best();
+    float wsum = 0.f;
+    for (int q = 0; q < beam; ++q) {
+        float wb = best;
+        int wi = bi;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            const float ob = __shfl_xor(wb, o, 64);
+            const int oi = __shfl_xor(wi, o, 64);
+            if (ob > wb || (ob == wb && oi < wi)) { wb = ob; wi = oi; }
+        }
+        if ((tid & 63) == 0) {
+            sv[q & 1][wave] = wb;
+            si[q & 1][wave] = wi;
+            if (q == 1) ssum[wave] = wsum;
         }
         __syncthreads();
-        if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
-        __syncthreads();
+        float gb = sv[q & 1][0];
+        int gi = si[q & 1][0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ob = sv[q & 1][w];
+            const int oi = si[q & 1][w];
+            if (ob > gb || (ob == gb && oi < gi)) { gb = ob; gi = oi; }
+        }
+        if (q == 0) {           // gb is the row maximum: this lane's share of the sum, over the values as loaded
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum += expf(r[j][e] - gb);
+            wsum = wave_sum(sum);
+            if (tid == 0) ssum[8] = gb;
+        }
+        if (q == 1 && tid == 0) lse[m] = ssum[8] + logf(ssum[0] + ssum[1] + ssum[2] + ssum[3]);
+        if (gi == 0x7fffffff) { gi = 0; gb = -INFINITY; }               // V < beam: fewer candidates than ranks
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
-            if (bi == 0x7fffffff) { bi = 0; best = -INFINITY; }         // V < beam: fewer candidates than ranks
-            cand_val[(int64_t)m * beam + q] = best;
-            cand_idx[(int64_t)m * beam + q] = bi;
-            s_pick = best == -INFINITY ? -1 : bi;
+            cand_val[(int64_t)m * beam + q] = gb;
+            cand_idx[(int64_t)m * beam + q] = gi;
         }
-        __syncthreads();
-        const int pick = s_pick;
-        if (pick >= 0 && ((pick >> 2) & 255) == tid) {                  // the lane that holds it takes it out of the running
+        if (gb != -INFINITY && ((gi >> 2) & 255) == tid) {              // the lane that holds it takes it out of the running
 #pragma unroll
             for (int j = 0; j < NV; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if ((j * 256 + tid) * 4 + e == pick) r[j][e] = -INFINITY;
+                    if ((j * 256 + tid) * 4 + e == gi) r[j][e] = -INFINITY;
+            lane_best();
         }
+    }
+    if (beam < 2) {             // no second round carried the sum
+        __syncthreads();
+        if ((tid & 63) == 0) ssum[wave] = wsum;
+        __syncthreads();
+        if (tid == 0) lse[m] = ssum[8] + logf(ssum[0] + ssum[1] + ssum[2] + ssum[3]);
     }
 }
 // Step 2: the `beam` best of the beam x beam candidates by score[k] + logit - lse[k]; writes the new scores, (parent,
