@@ -215,6 +215,14 @@ def test_configs4_beam_five_at_batch_128():
     # (random weights on running statistics (0, 1): 50 un-normalised layers amplify the bf16 difference between the GEMM tilings
     # of a 640-row and a 320-row decode -- measured 94 % equal captions, median score gap 1.0 nat at |score| ~ 22)
     assert np.median(np.abs(sh - s5[:64])) <= 0.1 * float(np.median(np.abs(s5[:64]))) and same >= 0.5
+    # the serving form: six batches (the batch, its images reversed, ...) through the two-stage pipeline, three decoders in flight
+    image_d = torch.as_tensor(image).to('cuda:0')
+    flipped = torch.flip(image_d, dims=[0]).contiguous()
+    five_flipped = eng.decode(flipped, beam=5, is_test=True).cpu().numpy().copy()
+    outs = eng.decode_pipelined([image_d, flipped] * 3, beam=5)
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        np.testing.assert_array_equal(o.cpu().numpy(), five_flipped if i % 2 else five)
     eng.check_sync()
     del eng
     torch.cuda.empty_cache()
