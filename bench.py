@@ -528,6 +528,15 @@ def main():
                                          frac_mfma=round(per['GFLOP'] * 1e9 / (avg_us * 1e-6) / 1e12 / profiling.PEAK_MFMA_TFLOPS['bf16'], 4), source=src)
         elif src:
             roof['rocprof_check'] = dict(source=src)
+        # ... and the same launches ALONE (idle device before each): what the kernel needs by itself against what it gets in the
+        # step -- the dominant symbol is a weight gradient on the lowest-priority lane under a bandwidth-bound backward pass
+        alone_ms, alone_n = profiling.time_label_alone([prog['fwd'], prog['bwd_opt']], name, eng._stream(), overhead_ms=over)
+        if alone_n:
+            per = roof['algorithmic_per_launch']
+            roof['alone'] = dict(avg_launch_us=round(alone_ms * 1e3, 2), launches=alone_n,
+                                 frac_hbm=round(per['MB'] * 1e6 / (alone_ms * 1e-3) / 1e9 / profiling.PEAK_HBM_GBPS, 4),
+                                 frac_mfma=round(per['GFLOP'] * 1e9 / (alone_ms * 1e-3) / 1e12 / profiling.PEAK_MFMA_TFLOPS['bf16'], 4),
+                                 note='the same launches one at a time on an idle device (operands as the step left them)')
         out['roofline'] = roof
         gemm = [(k, v) for k, v in top if v['flops'] > 0]
         # the largest MAIN-lane GEMM symbol next to it (the dominant symbol is a side-lane weight gradient)

@@ -181,6 +181,31 @@ def time_plan(plan, stream_ptr, repeats=1):
     return stats
 
 
+def time_label_alone(plans, label, stream_ptr, overhead_ms=0.0):
+    """Average duration of the launches labelled `label` (describe()) when each runs ALONE: the device is idle before every one of
+    them, the launch sits between two timing events on the caller's stream.  Next to time_step's in-model figure this says how much
+    of a kernel's time in the step is its own and how much is what running beside the other lane costs it.
+    -> (average ms, launches)"""
+    cur = torch.cuda.current_stream()
+    assert cur.cuda_stream == stream_ptr
+    total, n = 0.0, 0
+    for plan in plans:
+        for fn, name, args in plan.launches():
+            if not name.startswith(('capmi_igemm_', 'capmi_lstm_')) or describe(name, args)[0] != label:
+                continue
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            a.record(cur)
+            rc = fn(*[x.value if hasattr(x, 'value') and type(x).__name__ == 'PtrSlot' else x for x in args], stream_ptr)
+            b.record(cur)
+            torch.cuda.synchronize()
+            if rc != 0:
+                raise RuntimeError('%s failed during timing' % name)
+            total += max(a.elapsed_time(b) - overhead_ms, 0.0005)
+            n += 1
+    return (total / n if n else 0.0), n
+
+
 def event_pair_overhead_ms(stream_ptr, n=64):
     """What a PAIR of timing events around one launch adds to the interval they measure (the two barrier packets the command
     processor handles on either side of the kernel): the same n small fills timed once with a pair around each and once with
