@@ -320,6 +320,24 @@ int capmi_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, const void* 
 int capmi_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* saved_mean,
                             const float* saved_invstd, const float* scale, float* red, const float* acc8, const void* dy_scratch,
                             void* dx, int B, int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream);
+/* The stem of the ResNet encoders as the forward pass runs it on a bf16 engine: capmi_bn_stat_apply + capmi_maxpool3x3s2_fwd as ONE
+ * launch that never writes the activated tensor [B,Hi,Wi,C] -- it has one reader, the pool, and the backward pass needs only the sign
+ * of its elements.  x: the conv output; statistics as capmi_bn_stat_apply takes them (stat_rows / shift; parts in deterministic mode);
+ * pooled [B,Ho,Wo,C] and idx (uint8 argmax map) as capmi_maxpool3x3s2_fwd writes them -- bit for bit the two-launch result for the
+ * same statistics (every element is normalised, activated and rounded to bf16 before it is compared; first maximum wins).
+ * y_scratch [B,Hi,Wi,C]: written in deterministic mode only (capmi_bn_finalize + capmi_bn_apply + capmi_maxpool3x3s2_fwd).
+ * The backward pair for a layer run this way: capmi_bn_bwd_reduce_pool_x / capmi_bn_bwd_apply_pool_x = the _pool entry points with
+ * the activation's derivative formed from x, coef_a, saved_mean and offset (y = y_scratch: read in deterministic mode only). */
+int capmi_bn_stat_apply_pool(const void* x, float* parts, int part_rows, const float* stat_rows, const float* shift, int B, int Hi, int Wi, int C,
+                             int Ho, int Wo, const float* scale, const float* offset, float* run_mean, float* run_var, float momentum, float eps,
+                             float* saved_mean, float* saved_invstd, float* coef_a, int update_running, void* y_scratch, void* pooled, uint8_t* idx,
+                             int act, int dtype, void* stream);
+int capmi_bn_bwd_reduce_pool_x(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* coef_a, const float* offset,
+                               const float* saved_mean, const float* saved_invstd, float* ws, float* red, float* acc8, void* dy_scratch, int B,
+                               int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream);
+int capmi_bn_bwd_apply_pool_x(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* coef_a, const float* offset,
+                              const float* saved_mean, const float* saved_invstd, const float* scale, float* red, const float* acc8,
+                              const void* dy_scratch, void* dx, int B, int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream);
 /* Inference mode (fluid batch_norm is_test=True, the exported model of infer.py): mean = running mean,
  * coef_a = scale / sqrt(running variance + eps); follow with capmi_bn_apply. */
 int capmi_bn_inference_coef(const float* scale, const float* run_mean, const float* run_var, float eps, float* mean,
@@ -570,7 +588,7 @@ int capmi_allreduce_bucket_bf16(void* comm, void* buf16, int64_t n, void* stream
  * Returns 0, or the failing row's error (capmi_last_error names the row).  The host may patch argument slots between
  * runs (the per-step Adam step size). */
 enum { CAPMI_PLAN_LAUNCH = 0, CAPMI_PLAN_RECORD = 1, CAPMI_PLAN_WAIT = 2 };
-#define CAPMI_PLAN_MAX_ARGS 24
+#define CAPMI_PLAN_MAX_ARGS 32
 typedef struct {
     int32_t kind, lane, entry, nargs;
     uint64_t args[CAPMI_PLAN_MAX_ARGS];

@@ -47,6 +47,7 @@ SIGNATURES = {
     'capmi_igemm_nt_bnred': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p],
     'capmi_igemm_nt_stat': [_p, _p, _p, _g, _i, _i, _i, _p, _p, _p, _i, _p],
     'capmi_bn_stat_apply': [_p, _p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p],
+    'capmi_bn_stat_apply_pool': [_p, _p, _i, _p, _p, _i, _i, _i, _i, _i, _i, _p, _p, _p, _p, _f, _f, _p, _p, _p, _i, _p, _p, _p, _i, _i, _p],
     'capmi_igemm_nt_bnsum': [_p, _p, _p, _g, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p, _p, _p, _i, _p],
     'capmi_igemm_nt_group': [ctypes.POINTER(NtCall), _i, _i, _p],
     'capmi_igemm_nt_splitk': [_p, _p, _p, _i, _i, _i, _i, _i, _i, _p, ctypes.c_longlong, _i, _p],
@@ -73,7 +74,9 @@ SIGNATURES = {
     'capmi_bn_bwd_reduce_spread': [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_apply_spread': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p, _i, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_reduce_pool': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_bn_bwd_reduce_pool_x': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_bn_bwd_apply_pool': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    'capmi_bn_bwd_apply_pool_x': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     'capmi_add_act': [_p, _p, _p, _l, _i, _i, _p],
     'capmi_act_bwd': [_p, _p, _p, _i, _l, _i, _i, _p],
     'capmi_mean_rows': [_p, _p, _i, _i, _i, _i, _p],
@@ -159,7 +162,7 @@ COMM = {
 COMM_ID_BYTES = 128
 
 NLANES = 4                # lanes of a plan: 0 dependency chain, 1 weight gradients, 2 communication + optimizer, 3 projection-shortcut backward
-PLAN_MAX_ARGS = 24
+PLAN_MAX_ARGS = 32
 PLAN_LAUNCH, PLAN_RECORD, PLAN_WAIT = 0, 1, 2
 
 

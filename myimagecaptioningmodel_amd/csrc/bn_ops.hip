@@ -609,6 +609,159 @@ extern "C" int capmi_bn_stat_apply(const void* x, float* parts, int part_rows, c
     return 0;
 }
 
+// the bf16 (T) value the apply launch would have stored for conv output x: shared by capmi_bn_stat_apply_pool and its backward pair
+template <typename T, int ACT>
+__device__ __forceinline__ float pool_act_out(float x, float coef_a, float mean, float offset) {
+    return to_f32(from_f32<T>(apply_act(__builtin_fmaf(coef_a, x - mean, offset), ACT)));
+}
+
+// ------------------------------------------------------------------ finalize + apply + 3x3 / stride-2 max pool in one launch (the stem)
+// conv -> batch_norm -> relu -> pool2d(max, 3, 2, 1): the activated 112 x 112 tensor has ONE reader, the pool, and the backward pass
+// needs of it only the sign of every element (capmi_bn_bwd_*_pool_x form that from the conv output and the saved coefficients).  So
+// it is never written: a thread owns one pooled pixel x 8 channels, loads the nine conv-output vectors of its window up front (clamped
+// addresses, masked use), normalises / activates / rounds each to the bf16 the apply launch would have stored (pool_act_out) and keeps
+// the first maximum -- the values and the argmax map of capmi_bn_stat_apply + capmi_maxpool3x3s2_fwd.  Per step at cfg 2: 103 MB
+// written + 103 MB read less on the forward chain, 2 x 103 MB of reads less in the backward pair.  Prologue as bn_stat_apply_kernel's.
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_stat_apply_pool_kernel(const bf16* __restrict__ x, const float* __restrict__ rows, const float* __restrict__ shift, float inv_m,
+                                                                 const float* __restrict__ scale, const float* __restrict__ offset, float* run_mean, float* run_var,
+                                                                 float momentum, float eps, float* saved_mean, float* saved_invstd, float* coef_a, int update_running,
+                                                                 bf16* __restrict__ pooled, uint8_t* __restrict__ idx, int B, int Hi, int Wi, int C, int Ho, int Wo,
+                                                                 int rows_per_block) {
+    typedef bf16 T;
+    constexpr int VEC = 8;
+    const int cpr = C / VEC;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int j = t / cpr, cc = t - j * cpr;
+    if (j >= Wo) return;
+    f32x4 t0[4][2], t1[4][2], scv[2], ofv[2], rmv[2], rvv[2], shv[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            t0[r][q] = *reinterpret_cast<const f32x4*>(rows + (int64_t)r * 2 * C + cc * VEC + 4 * q);
+            t1[r][q] = *reinterpret_cast<const f32x4*>(rows + (int64_t)r * 2 * C + C + cc * VEC + 4 * q);
+        }
+    const bool writer = blockIdx.y == 0 && j == 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        scv[q] = *reinterpret_cast<const f32x4*>(scale + cc * VEC + 4 * q);
+        ofv[q] = *reinterpret_cast<const f32x4*>(offset + cc * VEC + 4 * q);
+        shv[q] = *reinterpret_cast<const f32x4*>(shift + cc * VEC + 4 * q);
+        if (writer && update_running) {
+            rmv[q] = *reinterpret_cast<const f32x4*>(run_mean + cc * VEC + 4 * q);
+            rvv[q] = *reinterpret_cast<const f32x4*>(run_var + cc * VEC + 4 * q);
+        }
+    }
+    const int r_begin = blockIdx.y * rows_per_block, r_end = min(B * Ho, r_begin + rows_per_block);
+    Vec<T> win[3][3];
+    bool ok[3][3];
+    auto load_row = [&](int r) {
+        const int b = r / Ho, ho = r - b * Ho;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int hi = 2 * ho - 1 + rr, wi = 2 * j - 1 + q;
+                ok[rr][q] = hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;
+                const int hc = min(max(hi, 0), Hi - 1), wc = min(max(wi, 0), Wi - 1);
+                win[rr][q] = vload<T>(x + ((((int64_t)b * Hi + hc) * Wi + wc) * cpr + cc) * VEC);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (r_begin < r_end) load_row(r_begin);
+    float a[VEC], bo[VEC], mu[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s0 += t0[r][v / 4][v % 4]; s1 += t1[r][v / 4][v % 4]; }
+        const float dm = s0 * inv_m;                                 // mean - shift
+        const float mean = shv[v / 4][v % 4] + dm;
+        const float var = fmaxf(s1 * inv_m - dm * dm, 0.f);          // biased
+        const float invstd = 1.f / sqrtf(var + eps);
+        mu[v] = mean;
+        a[v] = scv[v / 4][v % 4] * invstd;
+        bo[v] = ofv[v / 4][v % 4];
+        if (writer) {
+            const int c = cc * VEC + v;
+            saved_mean[c] = mean;
+            saved_invstd[c] = invstd;
+            coef_a[c] = a[v];
+            if (update_running) {
+                run_mean[c] = rmv[v / 4][v % 4] * momentum + mean * (1.f - momentum);
+                run_var[c] = rvv[v / 4][v % 4] * momentum + var * (1.f - momentum);
+            }
+        }
+    }
+    for (int r = r_begin; r < r_end; ++r) {
+        if (r != r_begin) load_row(r);
+        float best[VEC];
+        unsigned long long bi = 0;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) best[v] = -INFINITY;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (!ok[rr][q]) continue;
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float f = pool_act_out<T, ACT>(win[rr][q].get(v), a[v], mu[v], bo[v]);
+                    if (f > best[v]) {                                   // first maximum wins ties (capmi_maxpool3x3s2_fwd)
+                        best[v] = f;
+                        bi = (bi & ~(0xffull << (8 * v))) | ((unsigned long long)(rr * 3 + q) << (8 * v));
+                    }
+                }
+            }
+        Vec<T> ov;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) ov.set(v, best[v]);
+        const int64_t o = ((int64_t)r * Wo + j) * C + cc * VEC;
+        vstore<T>(pooled + o, ov);
+        *reinterpret_cast<unsigned long long*>(idx + o) = bi;
+    }
+}
+
+extern "C" int capmi_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* idx, int B, int Hi, int Wi, int C, int Ho, int Wo, int dtype, void* stream);
+
+/* capmi_bn_stat_apply + capmi_maxpool3x3s2_fwd as ONE launch that never writes the activated tensor (see above; capmi.h).
+ * y_scratch [B,Hi,Wi,C] is written in deterministic mode only, where the entry point IS the exact path: capmi_bn_finalize on the
+ * parts, capmi_bn_apply into y_scratch, capmi_maxpool3x3s2_fwd. */
+extern "C" int capmi_bn_stat_apply_pool(const void* x, float* parts, int part_rows, const float* stat_rows, const float* shift, int B, int Hi, int Wi, int C,
+                                        int Ho, int Wo, const float* scale, const float* offset, float* run_mean, float* run_var, float momentum, float eps,
+                                        float* saved_mean, float* saved_invstd, float* coef_a, int update_running, void* y_scratch, void* pooled, uint8_t* idx,
+                                        int act, int dtype, void* stream) {
+    CAPMI_CHECK(x && parts && stat_rows && shift && scale && offset && saved_mean && saved_invstd && coef_a && y_scratch && pooled && idx, "capmi_bn_stat_apply_pool: null pointer");
+    CAPMI_CHECK(shift != saved_mean, "capmi_bn_stat_apply_pool: the shift must not be the buffer the new mean is written to");
+    CAPMI_CHECK(!update_running || (run_mean && run_var), "capmi_bn_stat_apply_pool: running stats missing");
+    CAPMI_CHECK(dtype == CAPMI_BF16 && C % 8 == 0 && 256 % (C / 8) == 0, "capmi_bn_stat_apply_pool: bf16 tensors, C / 8 a divisor of 256 (C=%d dtype=%d)", C, dtype);
+    CAPMI_CHECK(act == CAPMI_ACT_RELU || act == CAPMI_ACT_RELU6, "capmi_bn_stat_apply_pool: the pooled layer's activation must be relu or relu6");
+    CAPMI_CHECK(Ho == (Hi + 1) / 2 && Wo == (Wi + 1) / 2, "capmi_bn_stat_apply_pool: 3x3 / stride 2 / pad 1 pooling of %dx%d gives %dx%d", Hi, Wi, (Hi + 1) / 2, (Wi + 1) / 2);
+    CAPMI_CHECK(((uintptr_t)stat_rows | (uintptr_t)shift | (uintptr_t)scale | (uintptr_t)offset | (uintptr_t)run_mean | (uintptr_t)run_var) % 16 == 0,
+                "capmi_bn_stat_apply_pool: per-channel vectors must be 16-byte aligned");
+    const int M = B * Hi * Wi;
+    if (capmi_deterministic()) {
+        if (capmi_bn_finalize(parts, part_rows, M, C, scale, run_mean, run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, stream)) return 1;
+        if (capmi_bn_apply(x, saved_mean, coef_a, offset, nullptr, y_scratch, M, C, act, dtype, stream)) return 1;
+        return capmi_maxpool3x3s2_fwd(y_scratch, pooled, idx, B, Hi, Wi, C, Ho, Wo, dtype, stream);
+    }
+    const int cpr = C / 8;
+    const int gx = cdiv(Wo * cpr, 256);
+    int rpb = cdiv((int64_t)B * Ho * gx, 4096);            // ~16 workgroups per CU, a few pooled rows each
+    if (rpb < 1) rpb = 1;
+    const dim3 grid(gx, cdiv(B * Ho, rpb));
+    const float inv_m = 1.f / (float)M;
+    if (act == CAPMI_ACT_RELU)
+        hipLaunchKernelGGL((bn_stat_apply_pool_kernel<CAPMI_ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stat_rows, shift, inv_m, scale, offset, run_mean,
+                           run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, (bf16*)pooled, idx, B, Hi, Wi, C, Ho, Wo, rpb);
+    else
+        hipLaunchKernelGGL((bn_stat_apply_pool_kernel<CAPMI_ACT_RELU6>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)x, stat_rows, shift, inv_m, scale, offset, run_mean,
+                           run_var, momentum, eps, saved_mean, saved_invstd, coef_a, update_running, (bf16*)pooled, idx, B, Hi, Wi, C, Ho, Wo, rpb);
+    CAPMI_LAUNCH_CHECK("capmi_bn_stat_apply_pool");
+    return 0;
+}
+
 // ------------------------------------------------------------------ backward
 // Stage 1: every workgroup reduces its row block to partial sums ws[block][2C] (plain stores).
 // Stage 2: red[0..C) += sum dz, red[C..2C) += sum dz*xhat over the partials (fixed order).
@@ -1054,10 +1207,13 @@ template <typename T> struct PoolWin {
     }
 };
 
-template <typename T, int ACT>
+// FROMX (capmi_bn_stat_apply_pool's backward): the activated tensor was never stored -- the activation's derivative comes from the
+// conv output and the layer's saved coefficients (pool_act_out: the very expression the forward kernel rounded and compared)
+template <typename T, int ACT, bool FROMX = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x,
                                                                  const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                 float* acc_rows, int B, int Hi, int Wi, int C, int Ho, int Wo, int rows_per_block) {
+                                                                 float* acc_rows, int B, int Hi, int Wi, int C, int Ho, int Wo, int rows_per_block,
+                                                                 const float* __restrict__ coef_a = nullptr, const float* __restrict__ offset = nullptr) {
     constexpr int VEC = Vec<T>::N;
     __shared__ float part[256 * VEC];
     const int cpr = C / VEC, Wb = (Wi + 1) >> 1, Hb = (Hi + 1) >> 1;
@@ -1066,9 +1222,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __rest
     const bool active = j < Wb;
     ColLayout L;
     L.cpc = cpr; L.rp = 256 / cpr; L.rows_per_block = 0;
-    float a1[VEC], a2[VEC], mu[VEC], is[VEC];
+    float a1[VEC], a2[VEC], mu[VEC], is[VEC], ca[VEC], of[VEC];
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) { a1[v] = 0.f; a2[v] = 0.f; mu[v] = mean[cc * VEC + v]; is[v] = invstd[cc * VEC + v]; }
+    for (int v = 0; v < VEC; ++v) {
+        a1[v] = 0.f; a2[v] = 0.f; mu[v] = mean[cc * VEC + v]; is[v] = invstd[cc * VEC + v];
+        ca[v] = FROMX ? coef_a[cc * VEC + v] : 0.f;
+        of[v] = FROMX ? offset[cc * VEC + v] : 0.f;
+    }
     const int r_end = min(B * Hb, (int)(blockIdx.y + 1) * rows_per_block);
     if (active)
         for (int r = blockIdx.y * rows_per_block; r < r_end; ++r) {
@@ -1082,12 +1242,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __rest
                     const int hi = 2 * i + a, wi = 2 * j + c;
                     if (hi >= Hi || wi >= Wi) continue;
                     const int64_t o = ((((int64_t)b * Hi + hi) * Wi + wi) * cpr + cc) * VEC;
-                    Vec<T> xv = vload<T>(x + o), yv = vload<T>(y + o);
+                    Vec<T> xv = vload<T>(x + o), yv;
+                    if constexpr (!FROMX) yv = vload<T>(y + o);
                     float g[VEC];
                     w.gather(a, c, g);
 #pragma unroll
                     for (int v = 0; v < VEC; ++v) {
-                        const float dz = g[v] * act_grad_from_out(yv.get(v), ACT);
+                        const float yo = FROMX ? pool_act_out<T, ACT>(xv.get(v), ca[v], mu[v], of[v]) : yv.get(v);
+                        const float dz = g[v] * act_grad_from_out(yo, ACT);
                         a1[v] += dz;
                         a2[v] += dz * (xv.get(v) - mu[v]) * is[v];
                     }
@@ -1108,11 +1270,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const T* __rest
 
 // One workgroup = rows_per_block rows of 2 x 2 blocks: the per-channel constants (16-byte loads, the accumulator rows among
 // them) are formed once per thread behind the first row's loads, as in bn_bwd_apply_kernel.
-template <typename T, int ACT>
+template <typename T, int ACT, bool FROMX = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restrict__ dpool, const uint8_t* __restrict__ idx, const T* __restrict__ x,
                                                                 const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                 const float* __restrict__ scale, const float* __restrict__ acc_rows, float* red_out, T* dx,
-                                                                int B, int Hi, int Wi, int C, int Ho, int Wo, int rows_per_block, float inv_m) {
+                                                                int B, int Hi, int Wi, int C, int Ho, int Wo, int rows_per_block, float inv_m,
+                                                                const float* __restrict__ coef_a = nullptr, const float* __restrict__ offset = nullptr) {
     constexpr int VEC = Vec<T>::N;
     const int cpr = C / VEC, Wb = (Wi + 1) >> 1, Hb = (Hi + 1) >> 1;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -1145,11 +1308,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restr
                 const int hi = min(2 * i + a, Hi - 1), wi = min(2 * j + c, Wi - 1);      // clamped: the store below is guarded
                 const int64_t o = ((((int64_t)b * Hi + hi) * Wi + wi) * cpr + cc) * VEC;
                 xv[a][c] = vload<T>(x + o);
-                yv[a][c] = vload<T>(y + o);
+                if constexpr (!FROMX) yv[a][c] = vload<T>(y + o);
             }
         __builtin_amdgcn_sched_barrier(0);
     };
-    float k1[VEC], c2[VEC], m0[VEC], mu[VEC];
+    float k1[VEC], c2[VEC], m0[VEC], mu[VEC], ca[VEC], of[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+        ca[v] = FROMX ? coef_a[cc * VEC + v] : 0.f;
+        of[v] = FROMX ? offset[cc * VEC + v] : 0.f;
+    }
     auto store_row = [&](int r) {
         const int b = r / Hb, i = r - b * Hb;
 #pragma unroll
@@ -1164,7 +1332,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const T* __restr
                 w.gather(a, c, g);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
-                    const float dz = g[v] * act_grad_from_out(yv[a][c].get(v), ACT);
+                    const float yo = FROMX ? pool_act_out<T, ACT>(xv[a][c].get(v), ca[v], muv[v / 4][v % 4], of[v]) : yv[a][c].get(v);
+                    const float dz = g[v] * act_grad_from_out(yo, ACT);
                     ov.set(v, k1[v] * ((dz - m0[v]) - (xv[a][c].get(v) - mu[v]) * c2[v]));
                 }
                 vstore<T>(dx + o, ov);
@@ -1196,9 +1365,9 @@ extern "C" int capmi_maxpool3x3s2_bwd(const void* dy, const uint8_t* idx, void* 
  * pass's argmax map; x / y: the layer's conv output and activated output [B,Hi,Wi,C]; acc: the layer's accumulator rows
  * (zeroed once per step).  dy_scratch [B,Hi,Wi,C] is written only in deterministic mode, where the pair IS the three-launch
  * path (capmi_maxpool3x3s2_bwd, then the two-stage reduction through ws / red). */
-extern "C" int capmi_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* saved_mean,
-                                        const float* saved_invstd, float* ws, float* red, float* acc, void* dy_scratch, int B, int Hi, int Wi, int C,
-                                        int Ho, int Wo, int act, int dtype, void* stream) {
+static int bn_bwd_reduce_pool_impl(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* coef_a, const float* offset,
+                                   const float* saved_mean, const float* saved_invstd, float* ws, float* red, float* acc, void* dy_scratch, int B, int Hi,
+                                   int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream) {
     CAPMI_CHECK(dpool && idx && x && y && saved_mean && saved_invstd && acc && dy_scratch, "capmi_bn_bwd_reduce_pool: null pointer");
     CAPMI_CHECK(act == CAPMI_ACT_RELU || act == CAPMI_ACT_RELU6, "capmi_bn_bwd_reduce_pool: the pooled layer's activation must be relu or relu6");
     const int M = B * Hi * Wi;
@@ -1215,15 +1384,31 @@ extern "C" int capmi_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, c
         int rpb = cdiv((int64_t)B * Hb * gx, wgs);         // ~4 workgroups per CU (256 adds per accumulator address)
         if (rpb < 1) rpb = 1;
         const dim3 grid(gx, cdiv(B * Hb, rpb));
-        if (act == CAPMI_ACT_RELU) hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T, CAPMI_ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, acc, B, Hi, Wi, C, Ho, Wo, rpb);
+        if (coef_a) {       // the activated tensor was never written (capmi_bn_stat_apply_pool): its sign comes from the conv output
+            if (act == CAPMI_ACT_RELU) hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T, CAPMI_ACT_RELU, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, acc, B, Hi, Wi, C, Ho, Wo, rpb, coef_a, offset);
+            else hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T, CAPMI_ACT_RELU6, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, acc, B, Hi, Wi, C, Ho, Wo, rpb, coef_a, offset);
+        } else if (act == CAPMI_ACT_RELU) hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T, CAPMI_ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, acc, B, Hi, Wi, C, Ho, Wo, rpb);
         else hipLaunchKernelGGL((bn_bwd_reduce_pool_kernel<T, CAPMI_ACT_RELU6>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, acc, B, Hi, Wi, C, Ho, Wo, rpb);
     });
     CAPMI_LAUNCH_CHECK("capmi_bn_bwd_reduce_pool");
     return 0;
 }
-extern "C" int capmi_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* saved_mean,
-                                       const float* saved_invstd, const float* scale, float* red, const float* acc, const void* dy_scratch, void* dx,
-                                       int B, int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream) {
+extern "C" int capmi_bn_bwd_reduce_pool(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* saved_mean,
+                                        const float* saved_invstd, float* ws, float* red, float* acc, void* dy_scratch, int B, int Hi, int Wi, int C,
+                                        int Ho, int Wo, int act, int dtype, void* stream) {
+    return bn_bwd_reduce_pool_impl(dpool, idx, x, y, nullptr, nullptr, saved_mean, saved_invstd, ws, red, acc, dy_scratch, B, Hi, Wi, C, Ho, Wo, act, dtype, stream);
+}
+// The pair behind capmi_bn_stat_apply_pool: y is the scratch tensor that entry point fills in deterministic mode only (read here in
+// that mode only); outside it the activation's derivative is formed from x, coef_a, saved_mean and offset (capmi.h).
+extern "C" int capmi_bn_bwd_reduce_pool_x(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* coef_a, const float* offset,
+                                          const float* saved_mean, const float* saved_invstd, float* ws, float* red, float* acc, void* dy_scratch, int B,
+                                          int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream) {
+    CAPMI_CHECK(coef_a && offset, "capmi_bn_bwd_reduce_pool_x: null pointer");
+    return bn_bwd_reduce_pool_impl(dpool, idx, x, y, coef_a, offset, saved_mean, saved_invstd, ws, red, acc, dy_scratch, B, Hi, Wi, C, Ho, Wo, act, dtype, stream);
+}
+static int bn_bwd_apply_pool_impl(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* coef_a, const float* offset,
+                                  const float* saved_mean, const float* saved_invstd, const float* scale, float* red, const float* acc, const void* dy_scratch,
+                                  void* dx, int B, int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream) {
     CAPMI_CHECK(dpool && idx && x && y && saved_mean && saved_invstd && scale && red && acc && dy_scratch && dx, "capmi_bn_bwd_apply_pool: null pointer");
     CAPMI_CHECK(act == CAPMI_ACT_RELU || act == CAPMI_ACT_RELU6, "capmi_bn_bwd_apply_pool: the pooled layer's activation must be relu or relu6");
     const int M = B * Hi * Wi;
@@ -1238,9 +1423,23 @@ extern "C" int capmi_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, co
         int rpb = cdiv((int64_t)B * Hb * gx, 4096);          // ~16 workgroups per CU, a few rows each
         if (rpb < 1) rpb = 1;
         const dim3 grid(gx, cdiv(B * Hb, rpb));
-        if (act == CAPMI_ACT_RELU) hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T, CAPMI_ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, acc, red, (T*)dx, B, Hi, Wi, C, Ho, Wo, rpb, 1.f / (float)M);
+        if (coef_a) {
+            if (act == CAPMI_ACT_RELU) hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T, CAPMI_ACT_RELU, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, acc, red, (T*)dx, B, Hi, Wi, C, Ho, Wo, rpb, 1.f / (float)M, coef_a, offset);
+            else hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T, CAPMI_ACT_RELU6, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, acc, red, (T*)dx, B, Hi, Wi, C, Ho, Wo, rpb, 1.f / (float)M, coef_a, offset);
+        } else if (act == CAPMI_ACT_RELU) hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T, CAPMI_ACT_RELU>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, acc, red, (T*)dx, B, Hi, Wi, C, Ho, Wo, rpb, 1.f / (float)M);
         else hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<T, CAPMI_ACT_RELU6>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)dpool, idx, (const T*)x, (const T*)y, saved_mean, saved_invstd, scale, acc, red, (T*)dx, B, Hi, Wi, C, Ho, Wo, rpb, 1.f / (float)M);
     });
     CAPMI_LAUNCH_CHECK("capmi_bn_bwd_apply_pool");
     return 0;
+}
+extern "C" int capmi_bn_bwd_apply_pool(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* saved_mean,
+                                       const float* saved_invstd, const float* scale, float* red, const float* acc, const void* dy_scratch, void* dx,
+                                       int B, int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream) {
+    return bn_bwd_apply_pool_impl(dpool, idx, x, y, nullptr, nullptr, saved_mean, saved_invstd, scale, red, acc, dy_scratch, dx, B, Hi, Wi, C, Ho, Wo, act, dtype, stream);
+}
+extern "C" int capmi_bn_bwd_apply_pool_x(const void* dpool, const uint8_t* idx, const void* x, const void* y, const float* coef_a, const float* offset,
+                                         const float* saved_mean, const float* saved_invstd, const float* scale, float* red, const float* acc,
+                                         const void* dy_scratch, void* dx, int B, int Hi, int Wi, int C, int Ho, int Wo, int act, int dtype, void* stream) {
+    CAPMI_CHECK(coef_a && offset, "capmi_bn_bwd_apply_pool_x: null pointer");
+    return bn_bwd_apply_pool_impl(dpool, idx, x, y, coef_a, offset, saved_mean, saved_invstd, scale, red, acc, dy_scratch, dx, B, Hi, Wi, C, Ho, Wo, act, dtype, stream);
 }

@@ -62,6 +62,7 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_igemm_nt_bnsum),
     CAPMI_ENTRY(capmi_igemm_nt_stat),
     CAPMI_ENTRY(capmi_bn_stat_apply),
+    CAPMI_ENTRY(capmi_bn_stat_apply_pool),
     CAPMI_ENTRY(capmi_igemm_tn_wgrad),
     CAPMI_ENTRY(capmi_colsum),
     CAPMI_ENTRY(capmi_im2col_stem),
@@ -86,6 +87,8 @@ const Entry g_entries[] = {
     CAPMI_ENTRY(capmi_bn_bwd_apply_spread),
     CAPMI_ENTRY(capmi_bn_bwd_reduce_pool),
     CAPMI_ENTRY(capmi_bn_bwd_apply_pool),
+    CAPMI_ENTRY(capmi_bn_bwd_reduce_pool_x),
+    CAPMI_ENTRY(capmi_bn_bwd_apply_pool_x),
     CAPMI_ENTRY(capmi_add_act),
     CAPMI_ENTRY(capmi_act_bwd),
     CAPMI_ENTRY(capmi_mean_rows),

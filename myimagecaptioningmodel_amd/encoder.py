@@ -163,6 +163,18 @@ class EncoderRunner:
         self.bn_spread = need_backward and os.environ.get('CAPMI_BN_SPREAD', '1') != '0'
         # max-pool backward gathered inside the producer's batch-norm backward (capmi_bn_bwd_reduce_pool); needs the accumulator rows
         self.pool_fuse = self.bn_spread and os.environ.get('CAPMI_POOL_FUSE', '1') != '0'
+        # ... and forward: capmi_bn_stat_apply + the pool as one launch that never writes the activated tensor (capmi_bn_stat_apply_pool); the
+        # backward pair then forms the activation's derivative from the conv output (capmi_bn_bwd_*_pool_x).  Decided here, once, for both passes.
+        self.pool_fwd = {}                  # tensor id (the conv + bn + relu output) -> the MaxPool that is its only reader
+        if self.pool_fuse and need_backward and self.code == 1 and os.environ.get('CAPMI_POOL_FWD_FUSE', '1') != '0' and os.environ.get('CAPMI_STAT_APPLY', '1') != '0':
+            prod_of = {o.dst: o for o in enc.ops if isinstance(o, arch.ConvBN)}
+            for o in enc.ops:
+                if isinstance(o, arch.MaxPool) and o.src in prod_of and id(prod_of[o.src]) not in self.skipped:
+                    pr, c = prod_of[o.src], self.shape[o.src][2]
+                    users = sum(1 for u in enc.ops if id(u) not in self.skipped and ((o.src in (u.a, u.b)) if isinstance(u, arch.Add) else u.src == o.src))
+                    if (pr.act in ('relu', 'relu6') and users == 1 and pr.groups == 1 and c % 8 == 0 and 256 % (c // 8) == 0 and o.src != enc.out
+                            and o.src not in self.fused_add and B * self.shape[o.src][0] * self.shape[o.src][1] > self.fa_max_rows):
+                        self.pool_fwd[o.src] = o
         # convolution + batch-norm statistics + finalize through ONE entry point (capmi_igemm_nt_bnfin: the last-arriving workgroup
         # finalizes when the library is built with -DCAPMI_FIN=1).  Measured slower than the dependent launch it removes (DESIGN.md
         # lesson 48): off by default.
@@ -190,7 +202,9 @@ class EncoderRunner:
                     h, w, c = self.shape[out_id]
                     # (layers whose finalize rides inside the apply launch -- capmi_bn_finalize_apply, CAPMI_BN_FA_MAXM -- write no bits:
                     # their data gradients keep reading the saved output)
-                    if act in ('relu', 'relu6') and c % 8 == 0 and c >= 32 and out_id != enc.out and B * h * w > self.fa_max_rows:
+                    # (... and a tensor whose only reader is a max pool is never written at all: capmi_bn_stat_apply_pool)
+                    if (act in ('relu', 'relu6') and c % 8 == 0 and c >= 32 and out_id != enc.out and B * h * w > self.fa_max_rows
+                            and out_id not in self.pool_fwd):
                         self.maskbits[out_id] = z((B * h * w * c // 8,), torch.uint8)
         self.bn_acc, off = {}, 0
         for op in enc.ops:
@@ -307,6 +321,7 @@ class EncoderRunner:
             self.coef_jobs = torch.from_numpy(table.view(np.uint8).reshape(-1)).to(self.dev)
             plan.add('capmi_bn_inference_coef_batched', _p(self.coef_jobs), len(convs), int(table[:, 5].max()), BN_EPS)
         deferred = []               # bn_apply launches moved off the forward chain (operand-path batch norm)
+        pooled_here = set()         # MaxPool ops whose output came out of their producer's apply launch (capmi_bn_stat_apply_pool)
         use_sa = self.stat_apply and not is_test and not self.bnfin
         if use_sa:
             plan.add('capmi_cast', _p(self.mean_all), _p(self.shift_all), self.mean_all.numel(), 0)      # (dtype code 0 = f32: a plain copy)
@@ -398,7 +413,17 @@ class EncoderRunner:
 
                 def apply(res, out, act, lane, out_id=None):
                     bits = self.maskbits.get(out_id) if (out_id is not None and not is_test) else None
-                    if sa:
+                    pool = self.pool_fwd.get(out_id) if (sa and res is None and not is_test and lane == 0) else None
+                    if pool is not None:
+                        # conv -> bn -> relu -> max pool: the activated tensor has one reader; it is never written (act[out_id] is the
+                        # deterministic mode's scratch), the pool's output and argmax map come out of this launch
+                        pho, pwo, _ = self.shape[pool.dst]
+                        plan.add('capmi_bn_stat_apply_pool', _p(raw), _p(bn['stats']), bn['part_rows'], sa_rows, _p(bn['shift']), B, ho, wo, c, pho, pwo,
+                                 _p(st.view(op.name + '_bn_scale')), offset, _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM,
+                                 BN_EPS, _p(bn['mean']), _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, out, _p(self.act[pool.dst]),
+                                 _p(self.pool_idx[pool.dst]), act, code, lane=lane)
+                        pooled_here.add(id(pool))
+                    elif sa:
                         plan.add('capmi_bn_stat_apply', _p(raw), _p(bn['stats']), bn['part_rows'], sa_rows, _p(bn['shift']), M, c, _p(st.view(op.name + '_bn_scale')), offset,
                                  _p(st.state[op.name + '_bn_mean']), _p(st.state[op.name + '_bn_variance']), BN_MOMENTUM, BN_EPS, _p(bn['mean']),
                                  _p(bn['invstd']), _p(bn['a']), 1 if update_running else 0, res, out, _p(bits), act, code, lane=lane)
@@ -426,7 +451,7 @@ class EncoderRunner:
             elif isinstance(op, arch.Add):
                 n = self.act[op.dst].numel()
                 plan.add('capmi_add_act', _p(self.act[op.a]), _p(self.act[op.b]), _p(self.act[op.dst]), n, ACT_CODES[op.act], code)
-            else:
+            elif id(op) not in pooled_here:
                 hi, wi, c = self.shape[op.src]
                 ho, wo, _ = self.shape[op.dst]
                 plan.add('capmi_maxpool3x3s2_fwd', _p(self.act[op.src]), _p(self.act[op.dst]), _p(self.pool_idx[op.dst]),
@@ -619,10 +644,18 @@ class EncoderRunner:
                     acc = self.bn_acc_all.data_ptr() + 4 * self.bn_acc[op.dst]
                     pho, pwo, _ = self.shape[pool.dst]
                     pargs = (B, ho, wo, c, pho, pwo, act, code)
-                    plan.add('capmi_bn_bwd_reduce_pool', _p(self.grad[pool.dst]), _p(self.pool_idx[pool.dst]), _p(raw), _p(y), _p(bn['mean']),
-                             _p(bn['invstd']), _p(self.bwd_ws), _p(red), acc, _p(self.grad[out_id]), *pargs)
-                    plan.add('capmi_bn_bwd_apply_pool', _p(self.grad[pool.dst]), _p(self.pool_idx[pool.dst]), _p(raw), _p(y), _p(bn['mean']),
-                             _p(bn['invstd']), _p(st.view(op.name + '_bn_scale')), _p(red), acc, _p(self.grad[out_id]), _p(draw), *pargs)
+                    if out_id in self.pool_fwd and self.stat_apply:
+                        # the forward pass never wrote y (capmi_bn_stat_apply_pool): the activation's derivative from the conv output
+                        cx = (_p(bn['a']), _p(st.view(op.name + '_bn_offset')))
+                        plan.add('capmi_bn_bwd_reduce_pool_x', _p(self.grad[pool.dst]), _p(self.pool_idx[pool.dst]), _p(raw), _p(y), *cx, _p(bn['mean']),
+                                 _p(bn['invstd']), _p(self.bwd_ws), _p(red), acc, _p(self.grad[out_id]), *pargs)
+                        plan.add('capmi_bn_bwd_apply_pool_x', _p(self.grad[pool.dst]), _p(self.pool_idx[pool.dst]), _p(raw), _p(y), *cx, _p(bn['mean']),
+                                 _p(bn['invstd']), _p(st.view(op.name + '_bn_scale')), _p(red), acc, _p(self.grad[out_id]), _p(draw), *pargs)
+                    else:
+                        plan.add('capmi_bn_bwd_reduce_pool', _p(self.grad[pool.dst]), _p(self.pool_idx[pool.dst]), _p(raw), _p(y), _p(bn['mean']),
+                                 _p(bn['invstd']), _p(self.bwd_ws), _p(red), acc, _p(self.grad[out_id]), *pargs)
+                        plan.add('capmi_bn_bwd_apply_pool', _p(self.grad[pool.dst]), _p(self.pool_idx[pool.dst]), _p(raw), _p(y), _p(bn['mean']),
+                                 _p(bn['invstd']), _p(st.view(op.name + '_bn_scale')), _p(red), acc, _p(self.grad[out_id]), _p(draw), *pargs)
                 elif id(op) in summed:
                     # the data gradient that completed dy took the sums in its epilogue: accumulator rows (or, deterministic, red) are final
                     assert act == NONE and not ln
@@ -794,6 +827,7 @@ class EncoderRunner:
                     done.add(id(op))
                     flush_marks()
                     continue
+                assert op.src not in self.pool_fwd, 'the forward pass never wrote this activated tensor: its backward must take the gathered pair'
                 plan.add('capmi_maxpool3x3s2_bwd', _p(self.grad[op.dst]), _p(self.pool_idx[op.dst]), _p(self.grad[op.src]), B, hi, wi, c, ho, wo, code)
                 written.add(op.src)
             done.add(id(op))

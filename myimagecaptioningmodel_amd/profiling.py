@@ -135,6 +135,11 @@ def describe(name, args):
     if name == 'capmi_bn_stat_apply':
         M, C, code = args[5], args[6], args[21]
         return 'bn_stat_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[17] else 2) + (M * C // 8 if args[19] else 0)
+    if name == 'capmi_bn_stat_apply_pool':
+        # (x, parts, part_rows, rows, shift, B, Hi, Wi, C, Ho, Wo, ...): the conv output read (each element by the windows that cover it: once
+        # from memory), the pooled tensor + its argmax map written
+        B_, Hi, Wi, C, Ho, Wo, code = args[5], args[6], args[7], args[8], args[9], args[10], args[25]
+        return 'bn_stat_apply_pool_kernel', 0.0, B_ * Hi * Wi * C * es_of(code) + B_ * Ho * Wo * C * (es_of(code) + 1)
     if name == 'capmi_bn_apply_mask':
         M, C, code = args[7], args[8], args[10]
         return 'bn_apply_kernel', 0.0, M * C * es_of(code) * (3 if args[4] else 2) + M * C // 8

@@ -216,7 +216,8 @@ def test_forward_statistics_path_in_the_engine(monkeypatch):
         eng.load_reference_params(params)
         loss = float(eng.forward_backward(imgs[0], caps[0]).cpu()[0])
         names = _names(eng._train[16]['fwd'])
-        out[on] = (loss, eng.export_reference_params(), names.count('capmi_bn_stat_apply'), names.count('capmi_bn_finalize'))
+        # (the stem's apply carries the max pool: capmi_bn_stat_apply_pool)
+        out[on] = (loss, eng.export_reference_params(), names.count('capmi_bn_stat_apply') + names.count('capmi_bn_stat_apply_pool'), names.count('capmi_bn_finalize'))
     (l1, p1, nsa1, nfin1), (l0, p0, nsa0, nfin0) = out['1'], out['0']
     assert nsa0 == 0 and nsa1 == 53 and nfin1 == 0 and nfin0 == 53, (nsa1, nfin1, nfin0)
     assert abs(l1 - l0) <= 2e-2, (l1, l0)            # (random initialisation: the bf16 engine itself is held to 5e-2 against the oracle)
@@ -254,3 +255,99 @@ def test_pipelined_decode_returns_the_ids_of_one_batch_at_a_time():
                 assert torch.equal(g, w)
     with pytest.raises(ValueError):
         eng.decode_pipelined([feeds[0][:, :, :32]], beam=1)          # a feed of another image size is refused, as in decode()
+
+
+@pytest.mark.parametrize('B,C,H,W', [(4, 64, 112, 112), (3, 64, 17, 23), (2, 32, 9, 12)])
+def test_stem_apply_and_max_pool_in_one_launch_and_its_backward_pair(B, C, H, W):
+    """capmi_bn_stat_apply_pool against capmi_bn_stat_apply + capmi_maxpool3x3s2_fwd on the SAME accumulator rows: pooled values, argmax
+    map and saved statistics bit for bit, the activated tensor never written; capmi_bn_bwd_reduce_pool_x / _apply_pool_x (activation
+    derivative from the conv output and the saved coefficients) against the pair that reads the activated tensor: the input gradient
+    bit for bit given the same sums, the sums to the order of their atomics; deterministic mode: the exact launches behind both."""
+    from myimagecaptioningmodel_amd import _lib
+    dev, bf, f32 = 'cuda:0', torch.bfloat16, torch.float32
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    rng = np.random.RandomState(B + C + H)
+    M = B * H * W
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    x = torch.tensor(rng.standard_normal((B, H, W, C)) * 1.5 + 0.3, dtype=f32, device=dev).to(bf)
+    scale = torch.tensor(rng.uniform(0.5, 1.5, C), dtype=f32, device=dev)
+    offset = torch.tensor(rng.standard_normal(C) * 0.3, dtype=f32, device=dev)
+    shift = torch.tensor(rng.standard_normal(C) * 0.1 + 0.3, dtype=f32, device=dev)
+    xf = x.float().reshape(M, C)
+    d = xf - shift
+    rows = torch.zeros((4, 2 * C), dtype=f32, device=dev)              # the sums the convolution's epilogue would have left, dealt over the four rows
+    for j in range(4):
+        rows[j, :C] = d[j::4].sum(0)
+        rows[j, C:] = (d[j::4] ** 2).sum(0)
+    parts = torch.zeros((64 * C * 2 + 1024,), dtype=f32, device=dev)
+    act = _lib.ACT_RELU
+
+    def stats():
+        return [torch.zeros(C, dtype=f32, device=dev) for _ in range(3)] + [torch.full((C,), 0.25, dtype=f32, device=dev), torch.full((C,), 2.0, dtype=f32, device=dev)]
+    # two launches
+    m2, i2, a2, rm2, rv2 = stats()
+    y2 = torch.zeros((B, H, W, C), dtype=bf, device=dev)
+    pool2 = torch.zeros((B, Ho, Wo, C), dtype=bf, device=dev)
+    idx2 = torch.zeros((B, Ho, Wo, C), dtype=torch.uint8, device=dev)
+    _lib.call('capmi_bn_stat_apply', p(x), p(parts), 128, p(rows), p(shift), M, C, p(scale), p(offset), p(rm2), p(rv2), 0.9, 1e-5, p(m2), p(i2), p(a2), 1, None, p(y2), None,
+              act, _lib.BF16, st)
+    _lib.call('capmi_maxpool3x3s2_fwd', p(y2), p(pool2), p(idx2), B, H, W, C, Ho, Wo, _lib.BF16, st)
+    # one launch
+    m1, i1, a1, rm1, rv1 = stats()
+    y1 = torch.full((B, H, W, C), float('nan'), dtype=bf, device=dev)
+    pool1 = torch.zeros((B, Ho, Wo, C), dtype=bf, device=dev)
+    idx1 = torch.full((B, Ho, Wo, C), 255, dtype=torch.uint8, device=dev)
+    _lib.call('capmi_bn_stat_apply_pool', p(x), p(parts), 128, p(rows), p(shift), B, H, W, C, Ho, Wo, p(scale), p(offset), p(rm1), p(rv1), 0.9, 1e-5, p(m1), p(i1), p(a1), 1,
+              p(y1), p(pool1), p(idx1), act, _lib.BF16, st)
+    torch.cuda.synchronize()
+    for u, v in ((m1, m2), (i1, i2), (a1, a2), (rm1, rm2), (rv1, rv2)):
+        assert torch.equal(u, v)
+    assert bool(torch.isnan(y1.float()).all())                          # the activated tensor is never written
+    assert torch.equal(pool1, pool2) and torch.equal(idx1, idx2)
+    # backward: the pair that reads y against the pair that reads x + coefficients
+    dpool = torch.tensor(rng.standard_normal((B, Ho, Wo, C)), dtype=f32, device=dev).to(bf)
+    bws = torch.zeros(L.capmi_bn_bwd_ws_floats(M, C, _lib.BF16), dtype=f32, device=dev)
+    scratch = torch.full((B, H, W, C), float('nan'), dtype=bf, device=dev)
+    geo = (B, H, W, C, Ho, Wo, act, _lib.BF16, st)
+    accy, redy, dxy = torch.zeros(16 * C, dtype=f32, device=dev), torch.zeros(2 * C, dtype=f32, device=dev), torch.zeros((B, H, W, C), dtype=bf, device=dev)
+    _lib.call('capmi_bn_bwd_reduce_pool', p(dpool), p(idx2), p(x), p(y2), p(m2), p(i2), p(bws), p(redy), p(accy), p(scratch), *geo)
+    _lib.call('capmi_bn_bwd_apply_pool', p(dpool), p(idx2), p(x), p(y2), p(m2), p(i2), p(scale), p(redy), p(accy), p(scratch), p(dxy), *geo)
+    accx, redx, dxx = torch.zeros(16 * C, dtype=f32, device=dev), torch.zeros(2 * C, dtype=f32, device=dev), torch.zeros((B, H, W, C), dtype=bf, device=dev)
+    _lib.call('capmi_bn_bwd_reduce_pool_x', p(dpool), p(idx1), p(x), p(y1), p(a1), p(offset), p(m1), p(i1), p(bws), p(redx), p(accx), p(scratch), *geo)
+    torch.cuda.synchronize()
+    sx, sy = accx[:8 * C].reshape(4, 2 * C).sum(0), accy[:8 * C].reshape(4, 2 * C).sum(0)
+    assert float((sx - sy).abs().max()) <= 1e-5 * max(1.0, float(sy.abs().max()))
+    accx.copy_(accy)                                                     # the same sums -> the same input gradient, bit for bit
+    _lib.call('capmi_bn_bwd_apply_pool_x', p(dpool), p(idx1), p(x), p(y1), p(a1), p(offset), p(m1), p(i1), p(scale), p(redx), p(accx), p(scratch), p(dxx), *geo)
+    torch.cuda.synchronize()
+    assert torch.equal(dxx, dxy) and torch.equal(redx, redy)
+    assert bool(torch.isnan(y1.float()).all()) and bool(torch.isnan(scratch.float()).all())
+    # deterministic mode: the exact path behind the same entry points (the scratch tensors are written there)
+    prev = _lib.set_deterministic(True)
+    try:
+        pr = L.capmi_bn_stats_part_rows(M, C, _lib.BF16)
+        nparts = (M + pr - 1) // pr
+        dparts = torch.zeros(((nparts + 64) * C * 2,), dtype=f32, device=dev)
+        _lib.call('capmi_bn_stats', p(x), M, C, p(dparts), _lib.BF16, st)
+        outs = []
+        for fused in (False, True):
+            m, i, a, rm, rv = stats()
+            y = torch.zeros((B, H, W, C), dtype=bf, device=dev)
+            po = torch.zeros((B, Ho, Wo, C), dtype=bf, device=dev)
+            ix = torch.zeros((B, Ho, Wo, C), dtype=torch.uint8, device=dev)
+            pc = dparts.clone()
+            if fused:
+                _lib.call('capmi_bn_stat_apply_pool', p(x), p(pc), pr, p(rows), p(shift), B, H, W, C, Ho, Wo, p(scale), p(offset), p(rm), p(rv), 0.9, 1e-5, p(m), p(i), p(a), 1,
+                          p(y), p(po), p(ix), act, _lib.BF16, st)
+            else:
+                _lib.call('capmi_bn_stat_apply', p(x), p(pc), pr, p(rows), p(shift), M, C, p(scale), p(offset), p(rm), p(rv), 0.9, 1e-5, p(m), p(i), p(a), 1, None, p(y), None,
+                          act, _lib.BF16, st)
+                _lib.call('capmi_maxpool3x3s2_fwd', p(y), p(po), p(ix), B, H, W, C, Ho, Wo, _lib.BF16, st)
+            torch.cuda.synchronize()
+            outs.append((m, i, a, rm, rv, y, po, ix))
+        for u, v in zip(*outs):
+            assert torch.equal(u, v)
+    finally:
+        _lib.set_deterministic(prev)
