@@ -599,6 +599,7 @@ class CaptionEngine:
                 self._eval_init(prog)
                 run(prog, 'graph_dec', prog['plan_dec'], D)
                 outs.append(prog['out'].clone())
+                outs[-1].record_stream(cur)             # allocated on the decoder's stream, read on the caller's
                 dec_done[i % depth] = torch.cuda.Event()
                 dec_done[i % depth].record(D)
         for st in [E] + Ds:
